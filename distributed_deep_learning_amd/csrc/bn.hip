@@ -1,0 +1,316 @@
+// Fused BatchNorm(+residual add)(+ReLU) for NHWC bf16 activations on gfx950.  All kernels are HBM-bound:
+// 16-byte (8 x bf16) accesses per lane, every thread keeps its channel chunk fixed so the per-channel
+// coefficients live in registers, and reductions go wave -> LDS -> a small [nslots][2][C] fp32 slab with float
+// atomics (the slab spreads same-address contention; a finalize kernel folds it).
+//
+// forward  (train): stats (or the conv epilogue's fused partials) -> finalize (mean, invstd, scale, shift,
+//                   running stats) -> apply  y = act(x*scale + shift [+ res])
+// backward        : reduce  (sum g, sum g*xhat with g = dy * [y > 0]) -> finalize (dgamma, dbeta, A, B, Cc)
+//                   -> apply dx = A*g + B*x + Cc  [dres = g]
+#include "common.h"
+#include "host_util.h"
+
+#define BN_SLOTS DDL_BN_SLOTS
+
+struct RowMap {
+  int cpb;    // chunk columns handled per block (<= 256)
+  int rp;     // rows per block pass
+  int c8;     // C / 8
+  int M;      // rows
+  int C;
+};
+
+static inline RowMap make_rowmap(int M, int C) {
+  RowMap r;
+  r.c8 = C / 8;
+  r.cpb = r.c8 <= 256 ? r.c8 : 256;
+  r.rp = 256 / r.cpb;
+  r.M = M;
+  r.C = C;
+  return r;
+}
+
+static inline dim3 rowmap_grid(const RowMap& r, int max_x = 2048) {
+  const int gy = (r.c8 + r.cpb - 1) / r.cpb;
+  long long gx = ((long long)r.M + r.rp * 4 - 1) / (r.rp * 4);   // >= 4 rows per thread when possible
+  if (gx < 1) gx = 1;
+  const int cap = max_x / gy > 0 ? max_x / gy : 1;
+  if (gx > cap) gx = cap;
+  return dim3((unsigned)gx, (unsigned)gy, 1);
+}
+
+// ---------------------------------------------------------------- forward: statistics
+__global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ slab,
+                                                       RowMap rm) {
+  __shared__ float red[256 * 16];
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  const bool active = (rg < rm.rp) && (chunk < rm.c8);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  if (active) {
+    for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)row * rm.C + (size_t)chunk * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[tid * 16 + q] = s1[q]; red[tid * 16 + 8 + q] = s2[q]; }
+  __syncthreads();
+  // thread (col, q, which) sums over row groups
+  const int nout = rm.cpb * 16;
+  for (int o = tid; o < nout; o += 256) {
+    const int c = o / 16, e = o % 16;          // e: 0..7 sum, 8..15 sumsq
+    const int ch = blockIdx.y * rm.cpb + c;
+    if (ch >= rm.c8) continue;
+    float s = 0.f;
+    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
+    const int which = e >> 3, q = e & 7;
+    const int slot = blockIdx.x % BN_SLOTS;
+    atomicAdd(&slab[((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q], s);
+  }
+}
+
+// slab [nslots][2][C] -> mean/invstd/scale/shift (+ running stats, PyTorch semantics: unbiased running var)
+__global__ void bn_finalize_kernel(const float* __restrict__ slab, int nslots, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int s = 0; s < nslots; ++s) {
+    s1 += slab[((size_t)s * 2 + 0) * C + c];
+    s2 += slab[((size_t)s * 2 + 1) * C + c];
+  }
+  const float mu = s1 / count;
+  float var = s2 / count - mu * mu;
+  var = fmaxf(var, 0.f);
+  const float is = rsqrtf(var + eps);
+  mean[c] = mu;
+  invstd[c] = is;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - mu * g * is;
+  if (running_mean) {
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+// ---------------------------------------------------------------- forward: apply
+template <bool RES, bool RELU>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
+                                                       bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, RowMap rm) {
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  if (rg >= rm.rp || chunk >= rm.c8) return;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { sc[q] = scale[chunk * 8 + q]; sh[q] = shift[chunk * 8 + q]; }
+  for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+    const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sh[q];
+    if (RES) {
+      const u32x4 rv = *reinterpret_cast<const u32x4*>(res + off);
+      float r[8];
+      unpack8(rv, r);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] += r[q];
+    }
+    if (RELU) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) f[q] = fmaxf(f[q], 0.f);
+    }
+    *reinterpret_cast<u32x4*>(y + off) = pack8(f);
+  }
+}
+
+// ---------------------------------------------------------------- backward: reductions
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                            const bf16_t* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, float* __restrict__ slab,
+                                                            RowMap rm) {
+  __shared__ float red[256 * 16];
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  const bool active = (rg < rm.rp) && (chunk < rm.c8);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  if (active) {
+    float mu[8], is[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { mu[q] = mean[chunk * 8 + q]; is[q] = invstd[chunk * 8 + q]; }
+    for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+      const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+      const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+      float g[8], xf[8];
+      unpack8(gv, g);
+      unpack8(xv, xf);
+      if (RELU) {
+        const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
+        float yf[8];
+        unpack8(yv, yf);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = yf[q] > 0.f ? g[q] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * (xf[q] - mu[q]) * is[q]; }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[tid * 16 + q] = s1[q]; red[tid * 16 + 8 + q] = s2[q]; }
+  __syncthreads();
+  const int nout = rm.cpb * 16;
+  for (int o = tid; o < nout; o += 256) {
+    const int c = o / 16, e = o % 16;
+    const int ch = blockIdx.y * rm.cpb + c;
+    if (ch >= rm.c8) continue;
+    float s = 0.f;
+    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
+    const int which = e >> 3, q = e & 7;
+    const int slot = blockIdx.x % BN_SLOTS;
+    atomicAdd(&slab[((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q], s);
+  }
+}
+
+// slab -> dgamma, dbeta and the three per-channel coefficients of dx = A*g + B*x + Cc
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nslots, int C, float count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, float* __restrict__ coefA,
+                                       float* __restrict__ coefB, float* __restrict__ coefC) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float sg = 0.f, sgx = 0.f;
+  for (int s = 0; s < nslots; ++s) {
+    sg += slab[((size_t)s * 2 + 0) * C + c];
+    sgx += slab[((size_t)s * 2 + 1) * C + c];
+  }
+  dgamma[c] = sgx;
+  dbeta[c] = sg;
+  const float g = gamma ? gamma[c] : 1.f;
+  const float sc = g * invstd[c];
+  const float mg = sg / count, mgx = sgx / count;
+  coefA[c] = sc;
+  coefB[c] = -sc * mgx * invstd[c];
+  coefC[c] = -sc * mg + sc * mgx * invstd[c] * mean[c];
+}
+
+template <bool RELU, bool DRES>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                           const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
+                                                           bf16_t* __restrict__ dres, const float* __restrict__ coefA,
+                                                           const float* __restrict__ coefB,
+                                                           const float* __restrict__ coefC, RowMap rm) {
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  if (rg >= rm.rp || chunk >= rm.c8) return;
+  float a[8], b[8], c[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { a[q] = coefA[chunk * 8 + q]; b[q] = coefB[chunk * 8 + q]; c[q] = coefC[chunk * 8 + q]; }
+  for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+    const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
+    const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+    float g[8], xf[8];
+    unpack8(gv, g);
+    unpack8(xv, xf);
+    if (RELU) {
+      const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
+      float yf[8];
+      unpack8(yv, yf);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = yf[q] > 0.f ? g[q] : 0.f;
+    }
+    if (DRES) *reinterpret_cast<u32x4*>(dres + off) = pack8(g);
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = a[q] * g[q] + b[q] * xf[q] + c[q];
+    *reinterpret_cast<u32x4*>(dx + off) = pack8(o);
+  }
+}
+
+// ================================================================ C ABI
+extern "C" int ddl_bn_slots() { return BN_SLOTS; }
+
+// slab: [BN_SLOTS][2][C] fp32 workspace (zeroed here).
+extern "C" int ddl_bn_stats(const void* x, float* slab, int M, int C, void* stream) {
+  if (C % 8 != 0 || M <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(slab, 0, sizeof(float) * BN_SLOTS * 2 * (size_t)C, st);
+  if (e != hipSuccess) return (int)e;
+  const RowMap rm = make_rowmap(M, C);
+  hipLaunchKernelGGL(bn_stats_kernel, rowmap_grid(rm), dim3(256), 0, st, (const bf16_t*)x, slab, rm);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ddl_bn_finalize(const float* slab, int nslots, int C, float count, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum,
+                               float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, nslots, C,
+                     count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int M,
+                            int C, int relu, void* stream) {
+  if (C % 8 != 0 || M <= 0) return -1;
+  const RowMap rm = make_rowmap(M, C);
+  const dim3 grid = rowmap_grid(rm);
+  hipStream_t st = (hipStream_t)stream;
+  const bf16_t* xp = (const bf16_t*)x; const bf16_t* rp = (const bf16_t*)res; bf16_t* yp = (bf16_t*)y;
+  if (res != nullptr) {
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+  } else {
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+  }
+  return (int)hipGetLastError();
+}
+
+// Full backward.  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
+extern "C" int ddl_bn_backward(const void* dy, const void* y, const void* x, const float* gamma, const float* mean,
+                               const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
+                               float* coef, int M, int C, int relu, void* stream) {
+  if (C % 8 != 0 || M <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(slab, 0, sizeof(float) * BN_SLOTS * 2 * (size_t)C, st);
+  if (e != hipSuccess) return (int)e;
+  const RowMap rm = make_rowmap(M, C);
+  const dim3 grid = rowmap_grid(rm);
+  const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* yp = (const bf16_t*)y; const bf16_t* xp = (const bf16_t*)x;
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
+  else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
+  float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
+                     mean, invstd, dgamma, dbeta, cA, cB, cC);
+  bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
+  if (relu) {
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+  } else {
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+  }
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,297 @@
+// Implicit-GEMM convolution for gfx950: forward and data-gradient share one gather-GEMM kernel.
+//
+//   out[m][oc] = sum_{r,s,ic} in[n, ih(m,r), iw(m,s), ic] * wmat[oc][(r*S+s)*IC + ic]
+//
+// All tensors are NHWC bf16, accumulation is fp32 on the MFMA pipe (v_mfma_f32_16x16x32_bf16).
+//   MODE 0 (fwd)  : rows m = output pixels (n,p,q); ih = p*stride - pad + r.
+//   MODE 1 (dgrad): rows m = input pixels (n,h,w); the gathered tensor is dy, ih = (h + pad - r)/stride
+//                   when divisible; wmat is the [C][R][S][K] repack of the filter.
+//
+// Tile: BM pixels x BN out-channels x BK=64 reduction, 256 threads = 4 waves (2 x 2), each wave owns a
+// (BM/2) x (BN/2) sub-tile.  The weight tile is the MFMA A operand and the pixel tile the B operand, so every
+// lane ends up with 4 consecutive output channels of one pixel (8-byte packed LDS store in the epilogue).
+// Staging is global -> registers -> LDS (the gather needs zero fill), double-buffered, one barrier per K-step;
+// the LDS image is XOR-swizzled in 16-byte chunks so both the ds_write_b128 and the ds_read_b128 fragment
+// reads are bank-conflict free.  The epilogue stages the bf16 tile through LDS for full-line stores and can
+// fuse bias+ReLU and the per-channel sum / sum-of-squares partials that BatchNorm needs (no extra read pass).
+#include "common.h"
+#include "host_util.h"
+
+struct ConvParams {
+  const bf16_t* in;
+  const bf16_t* wmat;
+  bf16_t* out;
+  const float* bias;   // optional [OC]
+  float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
+  int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;
+  int M, Kred;
+  int tiles_m, tiles_n;
+  int relu;
+};
+
+template <int BM, int BN, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+  constexpr int XI = BM / 32;
+  constexpr int WI = BN / 32;
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr int XBYTES = BM * 128, WBYTES = BN * 128;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const Xs = smem;
+  char* const Ws = smem + 2 * XBYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wm = wid & 1, wn = wid >> 1;
+
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / p.tiles_n, tile_n = lid - tile_m * p.tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  const int chunk = tid & 7, row0 = tid >> 3;
+
+  // ---- per-thread gather rows ----
+  int nb[XI], bh[XI], bw[XI];
+#pragma unroll
+  for (int i = 0; i < XI; ++i) {
+    const int m = m0 + row0 + 32 * i;
+    if (m < p.M) {
+      const int ohw = p.OH * p.OW;
+      const int n = m / ohw;
+      const int rem = m - n * ohw;
+      const int oh = rem / p.OW;
+      const int ow = rem - oh * p.OW;
+      nb[i] = n * p.IH * p.IW;
+      if (MODE == 0) { bh[i] = oh * p.stride - p.pad; bw[i] = ow * p.stride - p.pad; }
+      else           { bh[i] = oh + p.pad;            bw[i] = ow + p.pad; }
+    } else {
+      nb[i] = 0; bh[i] = -(1 << 28); bw[i] = -(1 << 28);
+    }
+  }
+  // ---- per-thread reduction cursor: kk = k0 + chunk*8 -> (r, s, c) ----
+  int kr, ks_, kc;
+  {
+    const int kk = chunk * 8;
+    const int tap = kk / p.IC;
+    kc = kk - tap * p.IC;
+    kr = tap / p.S;
+    ks_ = tap - kr * p.S;
+  }
+  int kkw = chunk * 8;
+
+  u32x4 xr[XI], wr[WI];
+
+  auto load_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      int ih, iw; bool ok;
+      if (MODE == 0) {
+        ih = bh[i] + kr; iw = bw[i] + ks_;
+        ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+      } else {
+        const int th = bh[i] - kr, tw = bw[i] - ks_;
+        if (p.stride == 1) {
+          ih = th; iw = tw;
+          ok = ((unsigned)th < (unsigned)p.IH) && ((unsigned)tw < (unsigned)p.IW);
+        } else if (p.stride == 2) {
+          ok = (th >= 0) && (tw >= 0) && (((th | tw) & 1) == 0);
+          ih = th >> 1; iw = tw >> 1;
+          ok = ok && (ih < p.IH) && (iw < p.IW);
+        } else {
+          ok = (th >= 0) && (tw >= 0);
+          ih = th / p.stride; iw = tw / p.stride;
+          ok = ok && (ih * p.stride == th) && (iw * p.stride == tw) && (ih < p.IH) && (iw < p.IW);
+        }
+      }
+      ok = ok && (kr < p.R);
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (ok) {
+        const size_t off = ((size_t)(nb[i] + ih * p.IW + iw)) * (size_t)p.IC + (size_t)kc;
+        v = *reinterpret_cast<const u32x4*>(p.in + off);
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int n = n0 + row0 + 32 * i;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (n < p.OC && kkw < p.Kred) {
+        v = *reinterpret_cast<const u32x4*>(p.wmat + (size_t)n * (size_t)p.Kred + (size_t)kkw);
+      }
+      wr[i] = v;
+    }
+  };
+  auto advance = [&]() {
+    kkw += 64;
+    kc += 64;
+    while (kc >= p.IC) {
+      kc -= p.IC;
+      if (++ks_ == p.S) { ks_ = 0; ++kr; }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int row = row0 + 32 * i;
+      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+      *reinterpret_cast<u32x4*>(Xs + buf * XBYTES + off) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+      const int row = row0 + 32 * i;
+      const int off = row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+      *reinterpret_cast<u32x4*>(Ws + buf * WBYTES + off) = wr[i];
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = (p.Kred + 63) >> 6;
+
+  load_tile();
+  advance();
+  store_tile(0);
+  __syncthreads();
+
+  for (int t = 0; t < ksteps; ++t) {
+    const int buf = t & 1;
+    const bool more = (t + 1 < ksteps);
+    if (more) { load_tile(); advance(); }
+    const char* xb = Xs + buf * XBYTES;
+    const char* wb = Ws + buf * WBYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[TN], b[TM];
+      const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WN + i * 16 + (lane & 15);
+        a[i] = *reinterpret_cast<const bf16x8*>(wb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm * WM + j * 16 + (lane & 15);
+        b[j] = *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc -> (bias, relu) -> bf16 tile in LDS -> full-line global stores (+ BN partial sums) ----
+  constexpr int OPITCH = (BN + 8) * 2;
+  char* const Os = smem;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int ch = wn * WN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = (n0 + ch + q < p.OC) ? p.bias[n0 + ch + q] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int px = wm * WM + j * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = acc[i][j][q] + bv[q];
+        if (p.relu) v[q] = fmaxf(v[q], 0.f);
+      }
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(Os + px * OPITCH + ch * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;       // 16-byte chunks per output row
+  constexpr int RPP = 256 / CPR;    // rows per pass
+  const int oc = tid % CPR, orow0 = tid / CPR;
+  const int ncol = n0 + oc * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+  for (int pass = 0; pass < BM / RPP; ++pass) {
+    const int row = orow0 + pass * RPP;
+    const int m = m0 + row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * OPITCH + oc * 16);
+    if (m < p.M && ncol < p.OC) {
+      *reinterpret_cast<u32x4*>(p.out + (size_t)m * (size_t)p.OC + (size_t)ncol) = v;
+      if (p.stats != nullptr) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+      }
+    }
+  }
+  if (p.stats != nullptr) {
+    constexpr int OS_BYTES = ((BM * OPITCH + 15) / 16) * 16;
+    float* const red = reinterpret_cast<float*>(smem + OS_BYTES);   // [RPP][2][BN]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
+      red[(orow0 * 2 + 1) * BN + oc * 8 + q] = s2[q];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid - which * BN;
+      float s = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
+      if (n0 + col < p.OC)
+        atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
+    }
+  }
+}
+
+template <int BM, int BN, int MODE>
+static int launch_conv(const ConvParams& p, hipStream_t stream) {
+  const int smem = 2 * (BM + BN) * 128;
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_igemm_kernel<BM, BN, MODE>), smem);
+  if (rc != 0) return rc;
+  const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, MODE>), dim3(grid), dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// mode: 0 = forward gather, 1 = dgrad gather.  Returns a hipError_t code (0 = ok), or negative for bad arguments.
+// `stats`, when not null, must hold DDL_BN_SLOTS * 2 * OC floats (it is zeroed here, then accumulated).
+
+extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
+                              int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              int pad, int relu, void* stream) {
+  if (IC % 8 != 0 || OC % 8 != 0) return -1;
+  if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0) return -2;
+  const long long M = (long long)N * OH * OW;
+  if (M >= (1ll << 31) || (long long)N * IH * IW >= (1ll << 31)) return -3;
+  ConvParams p;
+  p.in = (const bf16_t*)in; p.wmat = (const bf16_t*)wmat; p.out = (bf16_t*)out; p.bias = bias; p.stats = stats;
+  p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
+  p.stride = stride; p.pad = pad; p.M = (int)M; p.Kred = R * S * IC; p.relu = relu;
+  p.tiles_m = ((int)M + 127) / 128;
+  hipStream_t st = (hipStream_t)stream;
+  if (stats != nullptr) {
+    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * DDL_BN_SLOTS * 2 * (size_t)OC, st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (OC <= 64) {
+    p.tiles_n = (OC + 63) / 64;
+    return mode == 0 ? launch_conv<128, 64, 0>(p, st) : launch_conv<128, 64, 1>(p, st);
+  }
+  p.tiles_n = (OC + 127) / 128;
+  return mode == 0 ? launch_conv<128, 128, 0>(p, st) : launch_conv<128, 128, 1>(p, st);
+}

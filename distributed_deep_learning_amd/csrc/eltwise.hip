@@ -1,0 +1,216 @@
+// Element-wise and layout kernels (gfx950): all 16-byte vectorized, grid-stride, <= 2048 blocks.
+#include "common.h"
+#include "host_util.h"
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                            long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + i * 8);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(in + i * 8 + 4);
+    u32x4 o;
+    o[0] = pack_bf16x2(a[0], a[1]); o[1] = pack_bf16x2(a[2], a[3]);
+    o[2] = pack_bf16x2(b[0], b[1]); o[3] = pack_bf16x2(b[2], b[3]);
+    *reinterpret_cast<u32x4*>(out + i * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ in, float* __restrict__ out,
+                                                            long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(in + i * 8);
+    float f[8];
+    unpack8(v, f);
+    *reinterpret_cast<f32x4*>(out + i * 8) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(out + i * 8 + 4) = f32x4{f[4], f[5], f[6], f[7]};
+  }
+}
+
+// y = max(x, 0)
+__global__ __launch_bounds__(256) void relu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                       long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + i * 8);
+    float f[8];
+    unpack8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+    *reinterpret_cast<u32x4*>(y + i * 8) = pack8(f);
+  }
+}
+
+// dx = dy * [y > 0]
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                       bf16_t* __restrict__ dx, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 g = *reinterpret_cast<const u32x4*>(dy + i * 8);
+    const u32x4 v = *reinterpret_cast<const u32x4*>(y + i * 8);
+    float gf[8], yf[8];
+    unpack8(g, gf);
+    unpack8(v, yf);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) gf[e] = yf[e] > 0.f ? gf[e] : 0.f;
+    *reinterpret_cast<u32x4*>(dx + i * 8) = pack8(gf);
+  }
+}
+
+// out = a + b, optional ReLU
+template <bool RELU>
+__global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ b,
+                                                  bf16_t* __restrict__ out, long long n8) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const u32x4 va = *reinterpret_cast<const u32x4*>(a + i * 8);
+    const u32x4 vb = *reinterpret_cast<const u32x4*>(b + i * 8);
+    float fa[8], fb[8];
+    unpack8(va, fa);
+    unpack8(vb, fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { fa[e] += fb[e]; if (RELU) fa[e] = fmaxf(fa[e], 0.f); }
+    *reinterpret_cast<u32x4*>(out + i * 8) = pack8(fa);
+  }
+}
+
+// Per-channel bias gradient: db[c] = sum_m dy[m][c]  (dy bf16 [M][C], db fp32, accumulated with atomics; zeroed here)
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int M,
+                                                        int C, int c8) {
+  __shared__ float red[256 * 8];
+  const int cpb = c8 <= 256 ? c8 : 256;
+  const int rp = 256 / cpb;
+  const int col = threadIdx.x % cpb, rg = threadIdx.x / cpb;
+  const int chunk = blockIdx.y * cpb + col;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+  if (rg < rp && chunk < c8) {
+    for (int row = blockIdx.x * rp + rg; row < M; row += gridDim.x * rp) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dy + (size_t)row * C + (size_t)chunk * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += f[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+  __syncthreads();
+  for (int o = threadIdx.x; o < cpb * 8; o += 256) {
+    const int c = o / 8, e = o % 8;
+    const int ch = blockIdx.y * cpb + c;
+    if (ch >= c8) continue;
+    float s = 0.f;
+    for (int g = 0; g < rp; ++g) s += red[(g * cpb + c) * 8 + e];
+    atomicAdd(&db[(size_t)ch * 8 + e], s);
+  }
+}
+
+// Filter repack for dgrad: in fp32 or bf16 [K][RS][C]  ->  out bf16 [C][RS][K]  (+ optional bf16 copy [K][RS][C]).
+// 32x32 LDS-tiled transpose per filter tap; blockIdx.z = tap.
+template <typename TIN>
+__global__ __launch_bounds__(256) void filter_repack_kernel(const TIN* __restrict__ in, bf16_t* __restrict__ copy,
+                                                            bf16_t* __restrict__ outT, int K, int RS, int C) {
+  __shared__ bf16_t tile[32][33];
+  const int tap = blockIdx.z;
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + i * 8, c = c0 + tx;
+    bf16_t v = 0;
+    if (k < K && c < C) {
+      const size_t off = ((size_t)k * RS + tap) * C + c;
+      if constexpr (sizeof(TIN) == 4) v = f32_to_bf16(in[off]); else v = (bf16_t)in[off];
+      if (copy != nullptr) copy[off] = v;
+    }
+    tile[ty + i * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, k = k0 + tx;
+    if (c < C && k < K) outT[((size_t)c * RS + tap) * K + k] = tile[tx][ty + i * 8];
+  }
+}
+
+// NCHW fp32 -> NHWC bf16 with the channel axis zero-padded to Cp (input images: 3 -> 8)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                               int N, int C, int HW, int Cp, long long total) {
+  // one thread = one output pixel x 8 channels
+  const int cp8 = Cp / 8;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int ch = (int)(t % cp8);
+    const long long pix = t / cp8;
+    const int n = (int)(pix / HW);
+    const int hw = (int)(pix % HW);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = ch * 8 + e;
+      f[e] = c < C ? in[((size_t)n * C + c) * HW + hw] : 0.f;
+    }
+    *reinterpret_cast<u32x4*>(out + (size_t)pix * Cp + (size_t)ch * 8) = pack8(f);
+  }
+}
+
+extern "C" int ddl_cast_f32_bf16(const float* in, void* out, long long n, void* stream) {
+  if (n % 8 != 0) return -1;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     (bf16_t*)out, n / 8);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_cast_bf16_f32(const void* in, float* out, long long n, void* stream) {
+  if (n % 8 != 0) return -1;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in, out, n / 8);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_relu_fwd(const void* x, void* y, long long n, void* stream) {
+  if (n % 8 != 0) return -1;
+  hipLaunchKernelGGL(relu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                     (bf16_t*)y, n / 8);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_relu_bwd(const void* dy, const void* y, void* dx, long long n, void* stream) {
+  if (n % 8 != 0) return -1;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)y, (bf16_t*)dx, n / 8);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_add(const void* a, const void* b, void* out, long long n, int relu, void* stream) {
+  if (n % 8 != 0) return -1;
+  if (relu) hipLaunchKernelGGL((add_kernel<true>), dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 8);
+  else      hipLaunchKernelGGL((add_kernel<false>), dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                               (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 8);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_bias_grad(const void* dy, float* db, int M, int C, void* stream) {
+  if (C % 8 != 0 || M <= 0) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+  if (e != hipSuccess) return (int)e;
+  const int c8 = C / 8, cpb = c8 <= 256 ? c8 : 256, rp = 256 / cpb;
+  const int gy = (c8 + cpb - 1) / cpb;
+  long long gx = ((long long)M + rp * 8 - 1) / (rp * 8);
+  if (gx < 1) gx = 1;
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy, db, M, C, c8);
+  return (int)hipGetLastError();
+}
+// in_is_f32: 1 -> `in` is fp32 (master weights), 0 -> bf16.  copy may be null.
+extern "C" int ddl_filter_repack(const void* in, int in_is_f32, void* copy, void* outT, int K, int RS, int C,
+                                 void* stream) {
+  const dim3 grid((C + 31) / 32, (K + 31) / 32, RS);
+  if (in_is_f32)
+    hipLaunchKernelGGL((filter_repack_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, (const float*)in,
+                       (bf16_t*)copy, (bf16_t*)outT, K, RS, C);
+  else
+    hipLaunchKernelGGL((filter_repack_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                       (bf16_t*)copy, (bf16_t*)outT, K, RS, C);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, int HW, int Cp, void* stream) {
+  if (Cp % 8 != 0 || Cp < C) return -1;
+  const long long total = (long long)N * HW * (Cp / 8);
+  hipLaunchKernelGGL(nchw_to_nhwc_pad_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     (bf16_t*)out, N, C, HW, Cp, total);
+  return (int)hipGetLastError();
+}

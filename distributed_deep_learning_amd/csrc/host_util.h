@@ -1,0 +1,39 @@
+// Host-side helpers shared by the launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.h"
+
+static inline FastDiv make_fastdiv(unsigned int d) {
+  FastDiv f;
+  f.d = d;
+  if (d <= 1u) { f.magic = 0u; f.shift = 0u; return f; }
+  unsigned int s = 0;
+  while ((1ull << s) < (unsigned long long)d) ++s;           // s = ceil(log2 d), s >= 1
+  const unsigned long long num = 1ull << (31 + s);
+  f.magic = (unsigned int)((num + d - 1) / d);                // < 2^32 because 2^(s-1) < d
+  f.shift = s - 1;
+  return f;
+}
+
+// Dynamic-LDS opt-in, once per (kernel, device).
+struct SmemAttrOnce {
+  bool done[64] = {false};
+  int ensure(const void* fn, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (done[dev]) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done[dev] = true;
+    return 0;
+  }
+};
+
+static inline unsigned int grid_for(long long work_items, int per_block, int max_blocks = 2048) {
+  long long b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > max_blocks) b = max_blocks;
+  return (unsigned int)b;
+}

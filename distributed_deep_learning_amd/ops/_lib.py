@@ -1,0 +1,109 @@
+"""ctypes binding to ``lib/libddl_hip.so`` (the hand-written gfx950 kernel library).
+
+The library has a C ABI: raw device pointers, plain ints/floats and a ``hipStream_t``.  Every wrapper launches
+on torch's *current* HIP stream, so the kernels order correctly with ATen ops, with the RCCL communication
+streams of ``torch.distributed`` and inside ``torch.cuda.graph`` capture.
+
+There is deliberately no silent fallback: on a GPU box a missing library is an error (``require()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+
+import torch
+
+_PKG = Path(__file__).resolve().parent.parent
+LIB_PATH = _PKG / "lib" / "libddl_hip.so"
+
+_lib = None
+_load_error: Exception | None = None
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+_SIGS = {
+    "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp] + [_i] * 12 + [_vp],
+    "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
+    "ddl_bn_slots": [],
+    "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
+    "ddl_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _vp],
+    "ddl_maxpool_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
+    "ddl_maxpool_bwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
+    "ddl_avgpool_fwd": [_vp, _vp] + [_i] * 8 + [_vp],
+    "ddl_avgpool_bwd": [_vp, _vp] + [_i] * 8 + [_vp],
+    "ddl_gap_fwd": [_vp, _vp, _i, _i, _i, _vp],
+    "ddl_gap_bwd": [_vp, _vp, _i, _i, _i, _vp],
+    "ddl_cast_f32_bf16": [_vp, _vp, _ll, _vp],
+    "ddl_cast_bf16_f32": [_vp, _vp, _ll, _vp],
+    "ddl_relu_fwd": [_vp, _vp, _ll, _vp],
+    "ddl_relu_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "ddl_add": [_vp, _vp, _vp, _ll, _i, _vp],
+    "ddl_bias_grad": [_vp, _vp, _i, _i, _vp],
+    "ddl_filter_repack": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_nchw_to_nhwc_pad": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ddl_softmax_xent": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "ddl_chunk_elems": [],
+    "ddl_flat_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_flat_sgd": [_vp] * 9 + [_i, _i, _i, _vp],
+    "ddl_flat_adam": [_vp] * 8 + [_i, _i, _i, _vp],
+}
+
+
+def _load():
+    global _lib, _load_error
+    if _lib is not None or _load_error is not None:
+        return _lib
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+        for name, argtypes in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.argtypes = argtypes
+            fn.restype = _i
+        _lib = lib
+    except Exception as e:  # noqa: BLE001 - recorded and re-raised by require()
+        _load_error = e
+    return _lib
+
+
+def available() -> bool:
+    """True when the kernel library is loadable (it links libamdhip64, so this also works on a CPU box)."""
+    return _load() is not None
+
+
+def require():
+    lib = _load()
+    if lib is None:
+        raise RuntimeError(
+            f"HIP kernel library not loadable from {LIB_PATH}: {_load_error!r}. "
+            "Build it with `python -m distributed_deep_learning_amd.build`."
+        )
+    return lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: torch.Tensor | None):
+    return None if t is None else t.data_ptr()
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise HipKernelError(f"{what} failed with code {rc}" + (" (bad arguments)" if rc < 0 else " (hipError_t)"))
+
+
+def chunk_elems() -> int:
+    """Arena alignment quantum (elements); constant mirrored from csrc/optim.hip so CPU boxes need no .so."""
+    return 1024
+
+
+def bn_slots() -> int:
+    return 64

@@ -1,0 +1,328 @@
+"""Raw (non-autograd) Python entry points of the gfx950 kernel library.
+
+Conventions
+-----------
+* Activations are **bf16, logical NCHW, physically NHWC** (``torch.channels_last``).
+* Filters are logical ``[K, C, R, S]`` with channels-last strides, i.e. physically ``[K][R][S][C]`` ("KRSC");
+  the dgrad kernel wants the ``[C][R][S][K]`` repack ("CRSK") produced by :func:`filter_repack`.
+* Every function launches on the current HIP stream and allocates through torch's caching allocator, so
+  nothing here synchronises with the host.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+CL = torch.channels_last
+BF16 = torch.bfloat16
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Return ``x`` as a channels-last-contiguous tensor (no copy when it already is)."""
+    if x.dim() != 4:
+        raise ValueError(f"expected a 4-D NCHW tensor, got {tuple(x.shape)}")
+    return x if x.is_contiguous(memory_format=CL) else x.contiguous(memory_format=CL)
+
+
+def _chk_act(x: torch.Tensor, name: str) -> None:
+    if not x.is_cuda or x.dtype != BF16:
+        raise TypeError(f"{name}: expected a bf16 GPU tensor, got {x.dtype} on {x.device}")
+
+
+def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
+    return (h + 2 * pad - k) // stride + 1
+
+
+# ----------------------------------------------------------------------------------------------- conv
+def filter_repack(w: torch.Tensor, want_copy: bool = True):
+    """fp32/bf16 filter (logical KCRS, physically KRSC) -> (bf16 KRSC copy or None, bf16 CRSK repack)."""
+    lib = _lib.require()
+    K, Cc, R, S = w.shape
+    wp = w.permute(0, 2, 3, 1)
+    if not wp.is_contiguous():
+        wp = wp.contiguous()
+    is_f32 = w.dtype == torch.float32
+    if not is_f32 and w.dtype != BF16:
+        raise TypeError(f"filter_repack: unsupported dtype {w.dtype}")
+    copy = torch.empty((K, R, S, Cc), dtype=BF16, device=w.device) if (want_copy and is_f32) else None
+    wT = torch.empty((Cc, R, S, K), dtype=BF16, device=w.device)
+    check(lib.ddl_filter_repack(ptr(wp), int(is_f32), ptr(copy), ptr(wT), K, R * S, Cc, stream_ptr()), "filter_repack")
+    if copy is None and want_copy:
+        copy = wp
+    return copy, wT
+
+
+def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=False):
+    """x: bf16 NHWC activations; w_krsc: bf16 ``[K,R,S,C]`` contiguous.  Returns ``(y, stats_slab or None)``."""
+    lib = _lib.require()
+    _chk_act(x, "conv2d_fwd")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    K, R, S, C2 = w_krsc.shape
+    if C2 != Cc:
+        raise ValueError(f"conv2d_fwd: input has {Cc} channels, filter expects {C2}")
+    if w_krsc.dtype != BF16 or not w_krsc.is_contiguous():
+        raise TypeError("conv2d_fwd: filter must be a contiguous bf16 [K,R,S,C] tensor")
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    if P <= 0 or Q <= 0:
+        raise ValueError("conv2d_fwd: empty output")
+    y = torch.empty((N, K, P, Q), dtype=BF16, device=x.device, memory_format=CL)
+    stats = torch.empty((_lib.bn_slots(), 2, K), dtype=torch.float32, device=x.device) if want_stats else None
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
+        raise TypeError("conv2d_fwd: bias must be fp32 [K]")
+    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), N, P, Q, H, W, Cc, K, R, S,
+                             stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
+    return y, stats
+
+
+def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0):
+    """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC)."""
+    lib = _lib.require()
+    _chk_act(dy, "conv2d_dgrad")
+    dy = nhwc(dy)
+    N, K, P, Q = dy.shape
+    Cc, R, S, K2 = w_crsk.shape
+    if K2 != K:
+        raise ValueError("conv2d_dgrad: filter/grad channel mismatch")
+    H, W = in_hw
+    if conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
+        raise ValueError("conv2d_dgrad: geometry mismatch")
+    dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, N, H, W, P, Q, K, Cc, R, S, stride, pad,
+                             0, stream_ptr()), "conv2d_dgrad")
+    return dx
+
+
+def conv2d_wgrad(dy, x, R, S, stride=1, pad=0):
+    """Returns dw as an fp32 tensor of logical shape ``[K,C,R,S]`` with channels-last (KRSC) strides."""
+    lib = _lib.require()
+    _chk_act(dy, "conv2d_wgrad")
+    _chk_act(x, "conv2d_wgrad")
+    dy, x = nhwc(dy), nhwc(x)
+    N, K, P, Q = dy.shape
+    N2, Cc, H, W = x.shape
+    if N2 != N or conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
+        raise ValueError("conv2d_wgrad: geometry mismatch")
+    dw = torch.zeros((K, R, S, Cc), dtype=torch.float32, device=x.device)
+    check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(dw), N, H, W, Cc, K, P, Q, R, S, stride, pad, stream_ptr()),
+          "conv2d_wgrad")
+    return dw.permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------------------------- batch norm
+def bn_stats(x):
+    lib = _lib.require()
+    _chk_act(x, "bn_stats")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    slab = torch.empty((_lib.bn_slots(), 2, Cc), dtype=torch.float32, device=x.device)
+    check(lib.ddl_bn_stats(ptr(x), ptr(slab), N * H * W, Cc, stream_ptr()), "bn_stats")
+    return slab
+
+
+def bn_finalize(slab, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """slab ``[slots,2,C]`` -> ``vec[4,C]`` = (mean, invstd, scale, shift); updates running stats in place."""
+    lib = _lib.require()
+    Cc = slab.shape[-1]
+    vec = torch.empty((4, Cc), dtype=torch.float32, device=slab.device)
+    check(lib.ddl_bn_finalize(ptr(slab), slab.shape[0], Cc, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                              ptr(running_var), float(momentum), float(eps), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+                              ptr(vec[3]), stream_ptr()), "bn_finalize")
+    return vec
+
+
+def bn_apply(x, scale, shift, residual=None, relu=True):
+    lib = _lib.require()
+    _chk_act(x, "bn_apply")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    if residual is not None:
+        _chk_act(residual, "bn_apply(residual)")
+        residual = nhwc(residual)
+        if residual.shape != x.shape:
+            raise ValueError("bn_apply: residual shape mismatch")
+    y = torch.empty_like(x, memory_format=CL)
+    check(lib.ddl_bn_apply(ptr(x), ptr(residual), ptr(y), ptr(scale), ptr(shift), N * H * W, Cc, int(relu),
+                           stream_ptr()), "bn_apply")
+    return y
+
+
+def bn_backward(dy, y, x, gamma, mean, invstd, relu=True, want_dres=False):
+    """Returns ``(dx, dres or None, dgamma, dbeta)``; ``y`` (the forward output) is only read when ``relu``."""
+    lib = _lib.require()
+    _chk_act(dy, "bn_backward")
+    dy, x = nhwc(dy), nhwc(x)
+    if relu:
+        y = nhwc(y)
+    N, Cc, H, W = x.shape
+    dx = torch.empty_like(x, memory_format=CL)
+    dres = torch.empty_like(x, memory_format=CL) if want_dres else None
+    dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    work = torch.empty((_lib.bn_slots() * 2 + 3, Cc), dtype=torch.float32, device=x.device)
+    slab, coef = work[: _lib.bn_slots() * 2], work[_lib.bn_slots() * 2:]
+    check(lib.ddl_bn_backward(ptr(dy), ptr(y) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
+                              ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
+                              stream_ptr()), "bn_backward")
+    return dx, dres, dgb[0], dgb[1]
+
+
+# ----------------------------------------------------------------------------------------------- pooling
+def maxpool_fwd(x, k, stride, pad):
+    lib = _lib.require()
+    _chk_act(x, "maxpool_fwd")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    P, Q = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    y = torch.empty((N, Cc, P, Q), dtype=BF16, device=x.device, memory_format=CL)
+    idx = torch.empty((N, P, Q, Cc), dtype=torch.uint8, device=x.device)
+    check(lib.ddl_maxpool_fwd(ptr(x), ptr(y), ptr(idx), N, H, W, Cc, P, Q, k, stride, pad, stream_ptr()), "maxpool_fwd")
+    return y, idx
+
+
+def maxpool_bwd(dy, idx, in_hw, k, stride, pad):
+    lib = _lib.require()
+    dy = nhwc(dy)
+    N, Cc, P, Q = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+    check(lib.ddl_maxpool_bwd(ptr(dy), ptr(idx), ptr(dx), N, H, W, Cc, P, Q, k, stride, pad, stream_ptr()), "maxpool_bwd")
+    return dx
+
+
+def avgpool_fwd(x, k, stride):
+    lib = _lib.require()
+    _chk_act(x, "avgpool_fwd")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    P, Q = conv_out_size(H, k, stride, 0), conv_out_size(W, k, stride, 0)
+    y = torch.empty((N, Cc, P, Q), dtype=BF16, device=x.device, memory_format=CL)
+    check(lib.ddl_avgpool_fwd(ptr(x), ptr(y), N, H, W, Cc, P, Q, k, stride, stream_ptr()), "avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, in_hw, k, stride):
+    lib = _lib.require()
+    dy = nhwc(dy)
+    N, Cc, P, Q = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+    check(lib.ddl_avgpool_bwd(ptr(dy), ptr(dx), N, H, W, Cc, P, Q, k, stride, stream_ptr()), "avgpool_bwd")
+    return dx
+
+
+def gap_fwd(x):
+    """Global average pool: ``[N,C,H,W]`` -> ``[N,C]`` (bf16)."""
+    lib = _lib.require()
+    _chk_act(x, "gap_fwd")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    y = torch.empty((N, Cc), dtype=BF16, device=x.device)
+    check(lib.ddl_gap_fwd(ptr(x), ptr(y), N, H * W, Cc, stream_ptr()), "gap_fwd")
+    return y
+
+
+def gap_bwd(dy, in_hw):
+    lib = _lib.require()
+    dy = dy.contiguous()
+    N, Cc = dy.shape
+    H, W = in_hw
+    dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
+    check(lib.ddl_gap_bwd(ptr(dy), ptr(dx), N, H * W, Cc, stream_ptr()), "gap_bwd")
+    return dx
+
+
+# ----------------------------------------------------------------------------------------------- element-wise
+def _flat_ok(*ts):
+    n = ts[0].numel()
+    for t in ts:
+        if t.numel() != n or not (t.is_contiguous() or t.is_contiguous(memory_format=CL)):
+            raise ValueError("element-wise kernels need dense tensors of equal size")
+    if n % 8 != 0:
+        raise ValueError("element-wise kernels need numel % 8 == 0")
+    return n
+
+
+def relu_fwd(x):
+    lib = _lib.require()
+    n = _flat_ok(x)
+    y = torch.empty_like(x)
+    check(lib.ddl_relu_fwd(ptr(x), ptr(y), n, stream_ptr()), "relu_fwd")
+    return y
+
+
+def relu_bwd(dy, y):
+    lib = _lib.require()
+    if dy.stride() != y.stride():
+        dy = dy.contiguous(memory_format=CL) if y.is_contiguous(memory_format=CL) and y.dim() == 4 else dy.contiguous()
+    n = _flat_ok(dy, y)
+    dx = torch.empty_like(y)
+    check(lib.ddl_relu_bwd(ptr(dy), ptr(y), ptr(dx), n, stream_ptr()), "relu_bwd")
+    return dx
+
+
+def add(a, b, relu=False):
+    lib = _lib.require()
+    if a.stride() != b.stride():
+        b = b.contiguous(memory_format=CL) if a.is_contiguous(memory_format=CL) and a.dim() == 4 else b.contiguous()
+    n = _flat_ok(a, b)
+    out = torch.empty_like(a)
+    check(lib.ddl_add(ptr(a), ptr(b), ptr(out), n, int(relu), stream_ptr()), "add")
+    return out
+
+
+def bias_grad(dy):
+    """dy bf16 NHWC ``[N,K,P,Q]`` (or ``[M,K]``) -> fp32 ``[K]``."""
+    lib = _lib.require()
+    if dy.dim() == 4:
+        dy = nhwc(dy)
+        N, K, P, Q = dy.shape
+        M = N * P * Q
+    else:
+        dy = dy.contiguous()
+        M, K = dy.shape
+    db = torch.empty((K,), dtype=torch.float32, device=dy.device)
+    check(lib.ddl_bias_grad(ptr(dy), ptr(db), M, K, stream_ptr()), "bias_grad")
+    return db
+
+
+def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor | None = None):
+    lib = _lib.require()
+    n = src.numel()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=BF16, device=src.device)
+    check(lib.ddl_cast_f32_bf16(ptr(src), ptr(dst), n, stream_ptr()), "cast_f32_bf16")
+    return dst
+
+
+def nchw_to_nhwc_pad(x: torch.Tensor, cp: int):
+    """fp32 NCHW-contiguous images -> bf16 NHWC with channels zero-padded to ``cp`` (logical ``[N,cp,H,W]``)."""
+    lib = _lib.require()
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, cp, H, W), dtype=BF16, device=x.device, memory_format=CL)
+    check(lib.ddl_nchw_to_nhwc_pad(ptr(x), ptr(out), N, Cc, H * W, cp, stream_ptr()), "nchw_to_nhwc_pad")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- loss
+def softmax_xent(logits, target, want_grad=True):
+    """Returns ``(out[2] = (mean loss, top-1 hits), dlogits or None)``; target is int64 ``[B]`` or fp32 ``[B,V]``."""
+    lib = _lib.require()
+    logits = logits.contiguous()
+    B, V = logits.shape
+    if logits.dtype not in (BF16, torch.float32):
+        raise TypeError("softmax_xent: logits must be bf16 or fp32")
+    labels = probs = None
+    if target.dtype == torch.int64 and target.dim() == 1:
+        labels = target.contiguous()
+    else:
+        probs = target.to(torch.float32).contiguous()
+        if probs.shape != logits.shape:
+            raise ValueError("softmax_xent: probability targets must match the logits shape")
+    out = torch.empty((2,), dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib.ddl_softmax_xent(ptr(logits), int(logits.dtype == BF16), ptr(labels), ptr(probs), ptr(dl), ptr(out), B, V,
+                               stream_ptr()), "softmax_xent")
+    return out, dl

@@ -1,0 +1,211 @@
+"""Numerics of every hand-written gfx950 kernel against a plain PyTorch fp32 reference of the same op."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CL = torch.channels_last
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _rand_act(shape, seed, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = (torch.randn(shape, generator=g) * scale).to(torch.bfloat16)
+    return x.to(_dev()).contiguous(memory_format=CL)
+
+
+def _close(a, b, rtol=2e-2, atol=2e-2, what=""):
+    a, b = a.float(), b.float()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).sum().item()
+    assert bad == 0, f"{what}: {bad}/{a.numel()} mismatches, max err {err.max().item():.4g}, ref max {b.abs().max().item():.4g}"
+
+
+CONV_CASES = [
+    # N, C, H, W, K, R, stride, pad
+    (2, 64, 14, 14, 64, 1, 1, 0),
+    (2, 64, 14, 14, 256, 1, 1, 0),
+    (3, 256, 9, 9, 64, 1, 1, 0),       # M tail (243 rows)
+    (2, 128, 16, 16, 128, 3, 1, 1),
+    (2, 64, 17, 15, 64, 3, 2, 1),      # odd sizes, stride 2
+    (2, 256, 14, 14, 512, 1, 2, 0),    # strided 1x1 (downsample)
+    (2, 8, 32, 32, 64, 7, 2, 3),       # stem with padded channels
+    (2, 16, 12, 12, 24, 3, 1, 1),      # small channel counts, K tail
+    (1, 96, 8, 8, 128, 1, 1, 0),       # C not a multiple of 64
+    (2, 32, 10, 10, 72, 5, 1, 2),      # 5x5, OC tail
+    (4, 512, 7, 7, 512, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    N, C, H, W, Kc, R, stride, pad = case
+    x = _rand_act((N, C, H, W), 1)
+    w = (torch.randn((Kc, C, R, R), generator=torch.Generator().manual_seed(2)) / (C * R * R) ** 0.5)
+    w = w.to(_dev()).contiguous(memory_format=CL)
+    w_krsc, w_crsk = K.filter_repack(w)
+    wq = w_krsc.permute(0, 3, 1, 2).float()            # the bf16-rounded filter the kernels see
+    assert torch.equal(w_crsk.permute(3, 0, 1, 2).float(), wq), "CRSK repack mismatch"
+
+    y, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True)
+    y_ref = F.conv2d(x.float(), wq, None, stride, pad)
+    _close(y, y_ref, what="conv fwd")
+    # fused BN partial sums are computed from the rounded bf16 outputs
+    s = stats.sum(0)
+    yf = y.float()
+    _close(s[0], yf.sum((0, 2, 3)), rtol=1e-3, atol=1e-2 * max(1.0, yf.abs().max().item()), what="fused sum")
+    _close(s[1], (yf * yf).sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="fused sumsq")
+
+    dy = _rand_act(tuple(y.shape), 3)
+    dx = K.conv2d_dgrad(dy, w_crsk, (H, W), stride, pad)
+    dx_ref = torch.nn.grad.conv2d_input((N, C, H, W), wq, dy.float(), stride, pad)
+    _close(dx, dx_ref, what="conv dgrad")
+
+    dw = K.conv2d_wgrad(dy, x, R, R, stride, pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x.float(), (Kc, C, R, R), dy.float(), stride, pad)
+    scale = dw_ref.abs().max().item()
+    _close(dw, dw_ref, rtol=1e-2, atol=1e-2 * scale, what="conv wgrad")
+
+
+def test_conv_bias_relu_epilogue():
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    x = _rand_act((2, 64, 12, 12), 5)
+    w = torch.randn((128, 64, 3, 3), generator=torch.Generator().manual_seed(6)) / 24.0
+    w = w.to(_dev()).contiguous(memory_format=CL)
+    b = torch.randn(128, generator=torch.Generator().manual_seed(7)).to(_dev())
+    w_krsc, _ = K.filter_repack(w)
+    y, _ = K.conv2d_fwd(x, w_krsc, 1, 1, bias=b, relu=True)
+    ref = F.relu(F.conv2d(x.float(), w_krsc.permute(0, 3, 1, 2).float(), b, 1, 1))
+    _close(y, ref, what="conv+bias+relu")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 96, 7, 9), (3, 256, 5, 5), (2, 2048, 4, 4), (2, 4096, 2, 2)])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_bn_train_fwd_bwd(shape, relu, res):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    N, C, H, W = shape
+    x = _rand_act(shape, 11, scale=2.0) + 0.5
+    r = _rand_act(shape, 12) if res else None
+    g = torch.Generator().manual_seed(13)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(_dev())
+    beta = (torch.randn(C, generator=g) * 0.1).to(_dev())
+    rm, rv = torch.zeros(C, device=_dev()), torch.ones(C, device=_dev())
+    eps, mom = 1e-5, 0.1
+
+    slab = K.bn_stats(x)
+    vec = K.bn_finalize(slab, N * H * W, gamma, beta, rm, rv, mom, eps)
+    y = K.bn_apply(x, vec[2], vec[3], residual=r, relu=relu)
+
+    xf = x.float().requires_grad_(True)
+    rf = r.float().requires_grad_(True) if res else None
+    gp, bp = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm2, rv2 = torch.zeros(C, device=_dev()), torch.ones(C, device=_dev())
+    ref = F.batch_norm(xf, rm2, rv2, gp, bp, True, mom, eps)
+    if res:
+        ref = ref + rf
+    if relu:
+        ref = F.relu(ref)
+    _close(y, ref, what="bn fwd")
+    _close(rm, rm2, rtol=1e-3, atol=1e-4, what="running_mean")
+    _close(rv, rv2, rtol=1e-3, atol=1e-4, what="running_var")
+
+    dy = _rand_act(shape, 14)
+    # use the kernel's own y for the ReLU mask so rounding at 0 cannot flip elements between impls
+    dx, dres, dgamma, dbeta = K.bn_backward(dy, y, x, gamma, vec[0], vec[1], relu=relu, want_dres=res)
+    mask = (y.float() > 0).float() if relu else torch.ones_like(y, dtype=torch.float32)
+    # reference backward with the same mask: d(pre-relu) = dy * mask
+    pre = F.batch_norm(xf, None, None, gp, bp, True, mom, eps)
+    pre.backward(dy.float() * mask)
+    _close(dx, xf.grad, rtol=3e-2, atol=3e-2, what="bn dx")
+    scale = max(1.0, gp.grad.abs().max().item())
+    _close(dgamma, gp.grad, rtol=1e-2, atol=1e-2 * scale, what="dgamma")
+    _close(dbeta, bp.grad, rtol=1e-2, atol=1e-2 * scale, what="dbeta")
+    if res:
+        _close(dres, dy.float() * mask, what="dres")
+
+
+@pytest.mark.parametrize("k,stride,pad,shape", [(3, 2, 1, (2, 64, 16, 16)), (2, 2, 0, (2, 16, 8, 8)), (3, 2, 1, (1, 8, 7, 9))])
+def test_maxpool(k, stride, pad, shape):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    x = _rand_act(shape, 21)
+    x = torch.relu(x)  # plenty of ties at zero: exercises the first-max rule
+    y, idx = K.maxpool_fwd(x, k, stride, pad)
+    xf = x.float().requires_grad_(True)
+    ref = F.max_pool2d(xf, k, stride, pad)
+    assert torch.equal(y.float(), ref)
+    dy = _rand_act(tuple(y.shape), 22)
+    dx = K.maxpool_bwd(dy, idx, shape[2:], k, stride, pad)
+    ref.backward(dy.float())
+    _close(dx, xf.grad, what="maxpool bwd")
+
+
+def test_avgpool_and_gap():
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    x = _rand_act((2, 64, 8, 8), 31)
+    y = K.avgpool_fwd(x, 2, 2)
+    _close(y, F.avg_pool2d(x.float(), 2, 2), what="avgpool fwd")
+    dy = _rand_act(tuple(y.shape), 32)
+    dx = K.avgpool_bwd(dy, (8, 8), 2, 2)
+    xf = x.float().requires_grad_(True)
+    F.avg_pool2d(xf, 2, 2).backward(dy.float())
+    _close(dx, xf.grad, what="avgpool bwd")
+
+    x = _rand_act((3, 2048, 7, 7), 33)
+    g = K.gap_fwd(x)
+    _close(g, x.float().mean((2, 3)), what="gap fwd")
+    dg = torch.randn((3, 2048), device=_dev()).to(torch.bfloat16)
+    dx = K.gap_bwd(dg, (7, 7))
+    _close(dx, (dg.float() / 49.0)[:, :, None, None].expand(3, 2048, 7, 7), what="gap bwd")
+    x = _rand_act((2, 96, 5, 5), 34)
+    _close(K.gap_fwd(x), x.float().mean((2, 3)), what="gap fwd c96")
+
+
+def test_eltwise():
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    a, b = _rand_act((2, 64, 6, 6), 41), _rand_act((2, 64, 6, 6), 42)
+    _close(K.add(a, b, relu=True), F.relu(a.float() + b.float()), what="add_relu")
+    y = K.relu_fwd(a)
+    assert torch.equal(y.float(), F.relu(a.float()))
+    _close(K.relu_bwd(b, y), b.float() * (y.float() > 0), what="relu_bwd")
+    _close(K.bias_grad(a), a.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="bias_grad")
+    img = torch.randn((2, 3, 10, 10), device=_dev())
+    p = K.nchw_to_nhwc_pad(img, 8)
+    assert p.shape == (2, 8, 10, 10) and p.is_contiguous(memory_format=CL)
+    _close(p[:, :3], img, what="nchw->nhwc")
+    assert p[:, 3:].abs().max().item() == 0
+    f = torch.randn(4096, device=_dev())
+    assert torch.equal(K.cast_f32_bf16(f), f.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("B,V", [(32, 1000), (7, 10), (5, 6)])
+def test_softmax_xent(dtype, B, V):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    g = torch.Generator().manual_seed(51)
+    z = (torch.randn((B, V), generator=g) * 3).to(dtype).to(_dev())
+    lab = torch.randint(0, V, (B,), generator=g).to(_dev())
+    out, dz = K.softmax_xent(z, lab)
+    zf = z.float().requires_grad_(True)
+    ref = F.cross_entropy(zf, lab)
+    ref.backward()
+    assert abs(out[0].item() - ref.item()) < 2e-3 * max(1.0, abs(ref.item()))
+    assert out[1].item() == (zf.argmax(1) == lab).sum().item()
+    _close(dz, zf.grad, rtol=2e-2, atol=1e-4, what="xent grad")
+    # probability (one-hot float) targets: the reference repo's target format
+    probs = F.one_hot(lab, V).float()
+    out2, dz2 = K.softmax_xent(z, probs)
+    assert abs(out2[0].item() - ref.item()) < 2e-3 * max(1.0, abs(ref.item()))
+    _close(dz2, zf.grad, rtol=2e-2, atol=1e-4, what="xent grad (prob targets)")
