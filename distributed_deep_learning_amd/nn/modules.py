@@ -1,0 +1,245 @@
+"""Layers: thin subclasses of the torch modules (identical parameter names / shapes, so ``state_dict`` is
+interchangeable with stock PyTorch / torchvision) whose GPU forward runs the hand-written gfx950 kernels.
+
+Device dispatch, not backend dispatch: a CPU tensor (the gloo plumbing path, unit tests) takes the plain
+torch fp32 op; a GPU tensor takes the HIP kernels on bf16 channels-last data and *raises* if the kernel library
+is missing.  Filters keep an fp32 master in channels-last (KRSC) memory and a cached bf16 KRSC / CRSK pair
+that is refreshed whenever the master changes (``Parameter._version`` or :func:`ops.state.bump`).
+"""
+from __future__ import annotations
+
+import warnings
+
+import torch
+import torch.nn as tnn
+import torch.nn.functional as TF
+
+from ..ops import kernels as K
+from ..ops import state as _state
+from . import functional as F
+
+CL = torch.channels_last
+BF16 = torch.bfloat16
+
+
+def _pad8(c: int) -> int:
+    return (c + 7) // 8 * 8
+
+
+def to_device_input(x: torch.Tensor) -> torch.Tensor:
+    """Images -> what the GPU path wants: bf16, channels-last, channel count padded to a multiple of 8."""
+    if not x.is_cuda:
+        return x
+    c = x.shape[1]
+    cp = _pad8(c)
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return K.nchw_to_nhwc_pad(x, cp)
+    x = x.to(BF16)
+    if cp != c:
+        x = TF.pad(x, (0, 0, 0, 0, 0, cp - c))
+    return x.contiguous(memory_format=CL)
+
+
+class Conv2d(tnn.Conv2d):
+    """2-D convolution; GPU path = implicit-GEMM MFMA kernels (fwd / dgrad / wgrad)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.weight.data = self.weight.data.contiguous(memory_format=CL)
+        self._pack = None
+        self._warned = False
+
+    # ---- geometry the kernels support
+    def _native_ok(self) -> bool:
+        return (
+            self.groups == 1
+            and self.dilation == (1, 1)
+            and self.stride[0] == self.stride[1]
+            and self.padding[0] == self.padding[1]
+            and not isinstance(self.padding, str)
+            and self.padding_mode == "zeros"
+            and self.out_channels % 8 == 0
+        )
+
+    def packed(self):
+        """(bf16 KRSC, bf16 CRSK) with input channels zero-padded to a multiple of 8."""
+        w = self.weight
+        key = (w._version, _state.weights_epoch(), w.data_ptr(), w.device)
+        if self._pack is not None and self._pack[0] == key:
+            return self._pack[1], self._pack[2]
+        with torch.no_grad():
+            src = w.detach()
+            cin = src.shape[1]
+            if cin % 8 != 0:
+                src = TF.pad(src, (0, 0, 0, 0, 0, _pad8(cin) - cin)).contiguous(memory_format=CL)
+            elif not src.is_contiguous(memory_format=CL):
+                src = src.contiguous(memory_format=CL)
+            krsc, crsk = K.filter_repack(src)
+        self._pack = (key, krsc, crsk)
+        return krsc, crsk
+
+    def _fallback(self, x):
+        if not self._warned:
+            warnings.warn(f"Conv2d{tuple(self.weight.shape)}: geometry not covered by the HIP kernels, using ATen",
+                          stacklevel=3)
+            self._warned = True
+        y = TF.conv2d(x.to(self.weight.dtype), self.weight, self.bias, self.stride, self.padding, self.dilation,
+                      self.groups)
+        return y.to(BF16).contiguous(memory_format=CL) if x.is_cuda else y
+
+    def forward(self, x, relu: bool = False):
+        if not x.is_cuda:
+            y = super().forward(x)
+            return TF.relu(y) if relu else y
+        if not self._native_ok():
+            y = self._fallback(x)
+            return TF.relu(y) if relu else y
+        if x.shape[1] != _pad8(self.in_channels):
+            x = to_device_input(x)
+        krsc, crsk = self.packed()
+        return F.ConvBiasAct.apply(x, self.weight, self.bias, krsc, crsk, self.stride[0], self.padding[0], relu,
+                                   self.in_channels)
+
+
+class BatchNorm2d(tnn.BatchNorm2d):
+    """BatchNorm with optional fused residual add and ReLU: ``bn(x, residual=None, relu=False)``."""
+
+    def _eval_affine(self):
+        with torch.no_grad():
+            inv = torch.rsqrt(self.running_var.float() + self.eps)
+            g = self.weight.float() if self.affine else torch.ones_like(inv)
+            b = self.bias.float() if self.affine else torch.zeros_like(inv)
+            scale = g * inv
+            shift = b - self.running_mean.float() * scale
+        return scale, shift
+
+    def _momentum(self) -> float:
+        if self.momentum is None:
+            return 1.0 / float(self.num_batches_tracked.item() + 1)
+        return self.momentum
+
+    def forward(self, x, residual=None, relu: bool = False):
+        use_batch_stats = self.training or not self.track_running_stats
+        if (not x.is_cuda) or x.shape[1] % 8 != 0 or not self.affine:
+            y = super().forward(x.float() if x.is_cuda else x)
+            if residual is not None:
+                y = y + residual
+            if relu:
+                y = TF.relu(y)
+            return y.to(BF16).contiguous(memory_format=CL) if x.is_cuda else y
+        if use_batch_stats:
+            if self.training and self.track_running_stats:
+                self.num_batches_tracked += 1
+            return F.BNAct.apply(x, self.weight, self.bias, residual,
+                                 self.running_mean if self.track_running_stats else None,
+                                 self.running_var if self.track_running_stats else None,
+                                 self._momentum(), self.eps, relu)
+        scale, shift = self._eval_affine()
+        return F.AffineAct.apply(x, scale, shift, residual, relu)
+
+
+def conv_bn_act(conv: Conv2d, bn: BatchNorm2d, x, relu: bool = True, residual=None):
+    """conv -> BN -> (+residual) -> ReLU as ONE fused unit on the GPU (BN statistics come out of the conv
+    epilogue, no separate statistics pass); plain composition on the CPU."""
+    if (x.is_cuda and bn.training and bn.track_running_stats and bn.affine and conv.bias is None
+            and conv._native_ok()):
+        if x.shape[1] != _pad8(conv.in_channels):
+            x = to_device_input(x)
+        krsc, crsk = conv.packed()
+        bn.num_batches_tracked += 1
+        return F.ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, krsc, crsk, bn.running_mean,
+                                 bn.running_var, bn._momentum(), bn.eps, conv.stride[0], conv.padding[0], relu,
+                                 conv.in_channels)
+    return bn(conv(x), residual=residual, relu=relu)
+
+
+class ReLU(tnn.Module):
+    def __init__(self, inplace: bool = False):
+        super().__init__()
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == BF16 and x.numel() % 8 == 0:
+            return F.ReLU.apply(x)
+        return TF.relu(x)
+
+
+class MaxPool2d(tnn.MaxPool2d):
+    def forward(self, x):
+        k, s, p = self.kernel_size, self.stride, self.padding
+        simple = all(isinstance(v, int) for v in (k, s, p)) and self.dilation == 1 and not self.ceil_mode
+        if x.is_cuda and simple and x.shape[1] % 8 == 0 and not self.return_indices:
+            return F.MaxPool.apply(x, k, s, p)
+        return super().forward(x)
+
+
+class AvgPool2d(tnn.AvgPool2d):
+    def forward(self, x):
+        k, s = self.kernel_size, self.stride
+        simple = isinstance(k, int) and isinstance(s, int) and self.padding == 0 and s >= k and not self.ceil_mode
+        if x.is_cuda and simple and x.shape[1] % 8 == 0:
+            return F.AvgPool.apply(x, k, s)
+        return super().forward(x)
+
+
+class GlobalAvgPool2d(tnn.Module):
+    """``AdaptiveAvgPool2d(1)`` + ``flatten``: [N,C,H,W] -> [N,C]."""
+
+    def forward(self, x):
+        if x.is_cuda and x.shape[1] % 8 == 0:
+            return F.GlobalAvgPool.apply(x)
+        return x.mean((2, 3))
+
+
+class Linear(tnn.Linear):
+    """GPU path: bf16 hipBLASLt GEMM against a cached bf16 copy of the fp32 master weight."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._pack = None
+
+    def _w16(self):
+        w = self.weight
+        key = (w._version, _state.weights_epoch(), w.data_ptr(), w.device)
+        if self._pack is None or self._pack[0] != key:
+            self._pack = (key, w.detach().to(BF16))
+        return self._pack[1]
+
+    def forward(self, x, relu: bool = False):
+        if not x.is_cuda:
+            y = super().forward(x)
+        else:
+            if x.dim() > 2:
+                x = x.reshape(x.shape[0], -1)
+            y = F.Linear.apply(x, self.weight, self.bias, self._w16())
+        if relu:
+            y = F.ReLU.apply(y) if (y.is_cuda and y.numel() % 8 == 0) else TF.relu(y)
+        return y
+
+
+class Flatten(tnn.Module):
+    """Flatten in logical NCHW order (so classifier weights stay state_dict-compatible with NCHW models)."""
+
+    def forward(self, x):
+        return x.reshape(x.shape[0], -1)
+
+
+class SoftmaxCrossEntropyLoss(tnn.Module):
+    """Mean softmax cross-entropy on **logits**.  Targets: int64 class ids or fp32 probability rows (the
+    reference feeds one-hot floats, ``/root/reference/src/pytorch/CNN/dataset.py:108``).  ``forward`` returns
+    the loss; ``last_correct`` holds the top-1 hit count of the same launch (a device tensor, no host sync)."""
+
+    def __init__(self):
+        super().__init__()
+        self.last_correct = None
+
+    def forward(self, logits, target):
+        if logits.is_cuda:
+            loss, out = F.SoftmaxCrossEntropy.apply(logits, target)
+            self.last_correct = out[1]
+            return loss
+        lg = logits.float()
+        loss = TF.cross_entropy(lg, target)
+        with torch.no_grad():
+            t = target if target.dim() == 1 else target.argmax(1)
+            self.last_correct = (lg.argmax(1) == t).sum().float()
+        return loss
