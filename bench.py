@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ResNet-50 training throughput (images/sec, whole job) on synthetic 224x224 data, bf16 compute,
+random-init weights — the metric/config BASELINE.json names.
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One rank per GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  A step is the full
+training step: input conversion, forward, loss, backward with bucketed gradient all-reduce overlapped on RCCL's
+stream, fused SGD-momentum update of fp32 masters + bf16 shadow.  W untimed warm-up steps, then exactly K steps
+between barrier + synchronize on both sides; the reported time is the MAX over ranks.  Weak scaling: the per-GPU
+batch is fixed.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+# Same-box comparator measured with bench/stock_resnet.py (stock PyTorch-ROCm: MIOpen + ATen BN, bf16 autocast,
+# channels_last, cudnn.benchmark) at per-GPU batch 256 on one MI355X; see BASELINE.md / profiles/.
+STOCK_PYTORCH_1GPU_IMG_S = 6638.0
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch size")
+    ap.add_argument("--model", default="resnet50")
+    ap.add_argument("--sync", default="allreduce", choices=["allreduce", "ps"])
+    ap.add_argument("--optimizer", default="sgd", choices=["sgd", "lars"])
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--image", type=int, default=224)
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as td
+
+    from distributed_deep_learning_amd import dist as ddist
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import LARS, FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena
+
+    info = ddist.discover()
+    if info.world != a.gpus:
+        if info.world == 1 and a.gpus > 1:
+            print(f"bench.py: --gpus {a.gpus} needs a launcher (torch.distributed.run); running on 1 GPU", file=sys.stderr)
+        a.gpus = info.world
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible", file=sys.stderr)
+        return 2
+    dev = torch.device(f"cuda:{info.local_rank}")
+    ddist.init(info, dev)
+    torch.manual_seed(1234)
+
+    classes = 10 if a.model == "resnet18_cifar" else 1000
+    image = 32 if a.model == "resnet18_cifar" else a.image
+    model = models.build(a.model).to(dev)
+    ddp = None
+    if info.world > 1:
+        ddp = DistributedDataParallel(model, bucket_mb=a.bucket_mb, mode=a.sync)
+        arena = ddp.arena
+    else:
+        arena = ParamArena(model.named_parameters(), bucket_bytes=int(a.bucket_mb * 2**20))
+    if a.optimizer == "lars":
+        opt = LARS(arena, lr=0.1, momentum=0.9, weight_decay=5e-5)
+    else:
+        opt = FusedSGD(arena, lr=0.01, momentum=0.9, weight_decay=1e-4)
+    if ddp is not None:
+        ddp.attach(opt)
+    crit = SoftmaxCrossEntropyLoss()
+    fwd = ddp if ddp is not None else model
+
+    g = torch.Generator(device="cpu").manual_seed(100 + info.rank)
+    x = torch.randn(a.batch, 3, image, image, generator=g).to(dev)           # random data (zeros inflate clocks)
+    y = torch.randint(0, classes, (a.batch,), generator=g).to(dev)
+
+    def step():
+        loss = crit(fwd(x), y)
+        loss.backward()
+        if ddp is not None:
+            ddp.step(opt)
+        else:
+            opt.step()
+        return loss
+
+    def fence():
+        if info.world > 1:
+            td.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if info.world > 1:
+        td.all_reduce(t, op=td.ReduceOp.MAX)
+    dt = float(t.item())
+    final_loss = float(loss.detach().float().item())
+
+    if info.rank == 0:
+        gb = a.batch * info.world
+        value = gb * a.steps / dt
+        rec = {
+            "metric": "images/sec (whole job) ResNet-50 synthetic 224x224 training" if a.model == "resnet50"
+                      else f"images/sec (whole job) {a.model} training",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": info.world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random N(0,1) images, random-init weights)",
+            "config": {"model": a.model, "global_batch": gb, "per_gpu_batch": a.batch, "image": image, "seq_len": None,
+                       "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
+                       "bucket_mb": a.bucket_mb},
+            "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S, 3)
+                                             if a.model == "resnet50" and a.batch == 256 else None,
+            "final_loss": round(final_loss, 4),
+            "note": "reference publishes no numbers (BASELINE.md); comparator = stock PyTorch-ROCm measured on the same MI355X",
+        }
+        print(json.dumps(rec), flush=True)
+    ddist.shutdown()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -53,7 +53,15 @@ if __name__ == "__main__":
             loss = F.cross_entropy(model(x), y)
         loss.backward(); opt.step()
         return loss
-    for i in range(5): l = step()
+    import threading
+    def _hb():
+        n = 0
+        while not done.wait(30):
+            n += 30; print(f"[stock] warming up (MIOpen find) {n}s", flush=True)
+    done = threading.Event(); threading.Thread(target=_hb, daemon=True).start()
+    for i in range(5):
+        l = step(); torch.cuda.synchronize(); print("[stock] warm step", i, flush=True)
+    done.set()
     torch.cuda.synchronize(); t0 = time.time()
     for i in range(steps): l = step()
     torch.cuda.synchronize(); dt = (time.time() - t0) / steps

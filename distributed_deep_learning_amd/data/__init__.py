@@ -1,0 +1,7 @@
+from .loader import BatchLoader
+from .sampler import ShardedSampler, split_indices
+from .synthetic import (TensorDataset, WindowDataset, cifar_like, image_dataset, imagenet_like, mnist_like, pcb_like,
+                        tabular_dataset)
+
+__all__ = ["BatchLoader", "ShardedSampler", "split_indices", "TensorDataset", "WindowDataset", "cifar_like",
+           "image_dataset", "imagenet_like", "mnist_like", "pcb_like", "tabular_dataset"]

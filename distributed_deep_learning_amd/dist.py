@@ -1,0 +1,109 @@
+"""Process-group bootstrap and rank discovery: one process per GPU, ``torch.distributed`` over RCCL (the
+``"nccl"`` backend on ROCm) for GPU tensors and gloo for CPU tensors.
+
+Rank discovery honours, in order: explicit arguments, torchrun (``RANK/WORLD_SIZE/LOCAL_RANK``), Open MPI
+(``OMPI_COMM_WORLD_*`` — what the reference reads at ``/root/reference/src/pytorch/CNN/main.py:62-67``), SLURM.
+Unlike the reference nothing is hard-coded: no ``MASTER_ADDR='rtx2080-1.mit'`` / ``NCCL_SOCKET_IFNAME='enp3s0'``
+(``main.py:24-27,192-193``); rendezvous comes from the launcher's environment.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.distributed as td
+
+
+@dataclass
+class RankInfo:
+    rank: int = 0
+    world: int = 1
+    local_rank: int = 0
+    local_world: int = 1
+    launcher: str = "none"     # none | torchrun | mpi | slurm | spawn
+
+    @property
+    def distributed(self) -> bool:
+        return self.world > 1
+
+
+def discover(env=None) -> RankInfo:
+    e = os.environ if env is None else env
+    if "RANK" in e and "WORLD_SIZE" in e:
+        return RankInfo(int(e["RANK"]), int(e["WORLD_SIZE"]), int(e.get("LOCAL_RANK", 0)),
+                        int(e.get("LOCAL_WORLD_SIZE", e["WORLD_SIZE"])), "torchrun")
+    if "OMPI_COMM_WORLD_RANK" in e:
+        return RankInfo(int(e["OMPI_COMM_WORLD_RANK"]), int(e.get("OMPI_COMM_WORLD_SIZE", 1)),
+                        int(e.get("OMPI_COMM_WORLD_LOCAL_RANK", 0)), int(e.get("OMPI_COMM_WORLD_LOCAL_SIZE", 1)), "mpi")
+    if "SLURM_PROCID" in e and "SLURM_NTASKS" in e:
+        return RankInfo(int(e["SLURM_PROCID"]), int(e["SLURM_NTASKS"]), int(e.get("SLURM_LOCALID", 0)),
+                        int(e.get("SLURM_NTASKS_PER_NODE", "1").split("(")[0]), "slurm")
+    return RankInfo()
+
+
+def backend_for(device: torch.device) -> str:
+    return "nccl" if device.type == "cuda" else "gloo"
+
+
+def init(info: Optional[RankInfo] = None, device: Optional[torch.device] = None, timeout_s: float = 600.0,
+         master_addr: Optional[str] = None, master_port: Optional[int] = None) -> RankInfo:
+    """Initialise the default process group (no-op for world == 1).  Binds ``cuda:{local_rank}`` first so RCCL
+    opens its communicator on the right GPU (the reference leaves every non-``data`` rank on ``cuda:0``)."""
+    info = info or discover()
+    if device is not None and device.type == "cuda":
+        torch.cuda.set_device(device)
+    if info.world <= 1 or td.is_initialized():
+        return info
+    if master_addr is not None:
+        os.environ["MASTER_ADDR"] = master_addr
+    if master_port is not None:
+        os.environ["MASTER_PORT"] = str(master_port)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = backend_for(device or torch.device("cpu"))
+    kwargs = {}
+    if backend == "nccl" and device is not None:
+        kwargs["device_id"] = device
+    td.init_process_group(backend=backend, rank=info.rank, world_size=info.world,
+                          timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+    return info
+
+
+def is_dist() -> bool:
+    return td.is_available() and td.is_initialized() and td.get_world_size() > 1
+
+
+def rank() -> int:
+    return td.get_rank() if is_dist() else 0
+
+
+def world() -> int:
+    return td.get_world_size() if is_dist() else 1
+
+
+def barrier() -> None:
+    if is_dist():
+        td.barrier()
+
+
+def shutdown() -> None:
+    if td.is_available() and td.is_initialized():
+        try:
+            td.barrier()
+        finally:
+            td.destroy_process_group()
+
+
+def broadcast_flat(t: torch.Tensor, src: int = 0) -> None:
+    if is_dist():
+        td.broadcast(t, src)
+
+
+def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
+    if is_dist():
+        td.all_reduce(t, op=td.ReduceOp.SUM)
+    return t

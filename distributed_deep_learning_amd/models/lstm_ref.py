@@ -1,0 +1,43 @@
+"""The reference's LSTM workload (``/root/reference/src/pytorch/LSTM/model.py:70-94``): Conv1d(10->64, k=1)+ReLU,
+MaxPool1d(1)+ReLU (an identity), ``hidden_layers`` stacked LSTMs over the 64 conv channels as the time axis
+(input size 32 -> hidden), final hidden state -> Linear(hidden->5).  Trained with L1 loss + Adam
+(``/root/reference/src/pytorch/LSTM/main.py:163-164``).  Parity model: the recurrent cell is a plain library op
+(MIOpen RNN / ATen), it is not on the north-star hot path.  84,293 parameters at the defaults."""
+from __future__ import annotations
+
+import torch
+import torch.nn as tnn
+
+
+class LSTMRef(tnn.Module):
+    def __init__(self, hidden_layers=1, hidden_params=128, classes=5, history=10, features=32):
+        super().__init__()
+        if hidden_layers < 1:
+            raise ValueError("Model requires at least one hidden layer")
+        self.conv = tnn.Conv1d(history, 64, 1)
+        self.lstms = tnn.ModuleList(
+            tnn.LSTM(features if i == 0 else hidden_params, hidden_params, batch_first=True) for i in range(hidden_layers))
+        self.fc = tnn.Linear(hidden_params, classes)
+
+    def _front(self, x):
+        return torch.relu(torch.relu(self.conv(x.float())))     # conv+ReLU, MaxPool1d(1)+ReLU == ReLU
+
+    def _lstm(self, i, x):
+        out, (h, _c) = self.lstms[i](x)
+        return out if i + 1 < len(self.lstms) else h.squeeze(0)
+
+    def stages(self):
+        return [self._front] + [lambda x, i=i: self._lstm(i, x) for i in range(len(self.lstms))] + [self.fc]
+
+    def stage_modules(self):
+        from ..parallel.mp import FnStage
+        return [FnStage(f, m) for f, m in zip(self.stages(), [self.conv, *self.lstms, self.fc])]
+
+    def forward(self, x):
+        for s in self.stages():
+            x = s(x)
+        return x
+
+
+def lstm_ref(**kw):
+    return LSTMRef(**kw)

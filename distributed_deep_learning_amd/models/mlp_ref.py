@@ -1,0 +1,35 @@
+"""The reference's MLP workload: Linear(in->38)+ReLU, ``hidden_layers`` x [Linear(38->38)+ReLU], Linear(38->5)
+(``/root/reference/src/pytorch/MLP/model.py:51-59``); 48 input features for the MQTT data
+(``/root/reference/src/pytorch/MLP/dataset.py:33-37``).  Emits logits (the reference's trailing Softmax in front
+of CrossEntropyLoss is defect A5); 3,539 parameters at the default depth."""
+from __future__ import annotations
+
+import torch.nn as tnn
+
+from .. import nn as dnn
+
+
+class MLPRef(tnn.Module):
+    def __init__(self, input_size=48, hidden_layers=1, hidden_size=38, classes=5):
+        super().__init__()
+        if hidden_layers < 1:
+            raise ValueError("Model requires at least one hidden layer")
+        dims = [input_size] + [hidden_size] * (hidden_layers + 1)
+        self.hidden = tnn.ModuleList(dnn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
+        self.out = dnn.Linear(hidden_size, classes)
+
+    def stages(self):
+        return [lambda x, l=l: l(x, relu=True) for l in self.hidden] + [self.out]
+
+    def stage_modules(self):
+        from ..parallel.mp import FnStage
+        return [FnStage(f, m) for f, m in zip(self.stages(), [*self.hidden, self.out])]
+
+    def forward(self, x):
+        for s in self.stages():
+            x = s(x)
+        return x
+
+
+def mlp_ref(**kw):
+    return MLPRef(**kw)

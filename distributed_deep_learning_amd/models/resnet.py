@@ -124,6 +124,11 @@ class ResNet(tnn.Module):
         """Ordered list of callables (stem, layer1..4, head) for inter-layer partitioning."""
         return [self.stem, self.layer1, self.layer2, self.layer3, self.layer4, self.head]
 
+    def stage_modules(self):
+        from ..parallel.mp import FnStage
+        return [FnStage(self.stem, self.conv1, self.bn1, self.maxpool), self.layer1, self.layer2, self.layer3,
+                self.layer4, FnStage(self.head, self.avgpool, self.fc)]
+
     def forward(self, x):
         x = self.stem(x)
         x = self.layer1(x)

@@ -1,0 +1,203 @@
+"""Flat parameter arena: the memory layout everything distributed is built on.
+
+All parameters of a model (per device) live in ONE contiguous fp32 master buffer, with three siblings of the
+same layout: gradients (fp32), optimizer state, and — on the GPU — a bf16 shadow the conv kernels read.
+``Parameter.data`` / ``Parameter.grad`` become strided views into the arena (memory format preserved, so
+``state_dict`` is unchanged).  Consequences, all chosen for MI355X (288 GB HBM, 7 xGMI links per GPU):
+
+* gradient buckets are contiguous arena ranges -> RCCL all-reduce / reduce-scatter / all-gather run in place on
+  them, no pack / unpack / flatten copies, few large collectives;
+* the "multi-tensor" optimizer is a single kernel launch over the range (csrc/optim.hip) which also rewrites the
+  bf16 shadow and clears the gradient;
+* the PS-style (ZeRO-1) mode shards each bucket evenly: buckets are padded to ``shard_multiple`` chunks.
+
+Layout: tensors start on ``CHUNK``-element boundaries; consecutive tensors are grouped into buckets of about
+``bucket_bytes`` (the LAST bucket — first to become ready in backward — is kept smaller so communication starts
+early); each bucket is padded to a multiple of ``CHUNK * shard_multiple``.
+
+Reference: replaces the per-parameter ``all_reduce`` loop of ``/root/reference/src/pytorch/CNN/main.py:136-139``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Iterable, List, Optional, Sequence
+
+import torch
+
+from ..ops import _lib
+
+CHUNK = _lib.chunk_elems()
+
+
+@dataclass
+class Segment:
+    """One parameter tensor inside the arena."""
+    index: int
+    name: str
+    offset: int          # element offset of the tensor
+    numel: int
+    padded: int          # elements reserved (multiple of CHUNK)
+    bucket: int
+
+
+@dataclass
+class Bucket:
+    index: int
+    lo: int              # element range [lo, hi) — hi includes the shard padding
+    hi: int
+    segments: List[int]
+
+
+def _ceil_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+def plan_buckets(sizes: Sequence[int], bucket_elems: int, first_bucket_elems: Optional[int] = None) -> List[List[int]]:
+    """Group tensor indices (registration order) into buckets.  Buckets are filled from the END of the list,
+    because backward produces gradients in reverse registration order; the bucket that becomes ready first is
+    capped at ``first_bucket_elems`` so its collective starts early.  Returns buckets in registration order."""
+    if first_bucket_elems is None:
+        first_bucket_elems = max(bucket_elems // 4, 1)
+    buckets: List[List[int]] = []
+    cur: List[int] = []
+    cur_elems = 0
+    cap = first_bucket_elems
+    for i in range(len(sizes) - 1, -1, -1):
+        cur.append(i)
+        cur_elems += sizes[i]
+        if cur_elems >= cap:
+            buckets.append(list(reversed(cur)))
+            cur, cur_elems, cap = [], 0, bucket_elems
+    if cur:
+        buckets.append(list(reversed(cur)))
+    buckets.reverse()
+    return buckets
+
+
+class ParamArena:
+    def __init__(self, named_params: Iterable, bucket_bytes: int = 32 << 20, shard_multiple: int = 1,
+                 shadow: Optional[bool] = None, first_bucket_bytes: Optional[int] = None):
+        named = [(n, p) for n, p in named_params if p.requires_grad]
+        if not named:
+            raise ValueError("ParamArena: no trainable parameters")
+        dev = named[0][1].device
+        for n, p in named:
+            if p.device != dev:
+                raise ValueError(f"ParamArena: parameter {n} is on {p.device}, expected {dev} (one arena per device)")
+            if p.dtype != torch.float32:
+                raise TypeError(f"ParamArena: parameter {n} must be fp32 (master weights), got {p.dtype}")
+        self.device = dev
+        self.shard_multiple = int(shard_multiple)
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
+        padded = [_ceil_to(p.numel(), CHUNK) for p in self.params]
+        groups = plan_buckets(padded, max(bucket_bytes // 4, CHUNK),
+                              None if first_bucket_bytes is None else max(first_bucket_bytes // 4, CHUNK))
+        self.segments: List[Segment] = [None] * len(self.params)  # type: ignore[list-item]
+        self.buckets: List[Bucket] = []
+        off = 0
+        for b, idxs in enumerate(groups):
+            lo = off
+            for i in idxs:
+                self.segments[i] = Segment(i, self.names[i], off, self.params[i].numel(), padded[i], b)
+                off += padded[i]
+            off = lo + _ceil_to(off - lo, CHUNK * self.shard_multiple)
+            self.buckets.append(Bucket(b, lo, off, list(idxs)))
+        self.total = off
+        self.nchunks = self.total // CHUNK
+
+        self.master = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=dev)
+        use_shadow = dev.type == "cuda" if shadow is None else shadow
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=dev) if use_shadow else None
+
+        chunk_seg = torch.full((self.nchunks,), -1, dtype=torch.int32)
+        for s in self.segments:
+            chunk_seg[s.offset // CHUNK:(s.offset + s.padded) // CHUNK] = s.index
+        self.chunk_seg = chunk_seg.to(dev)
+
+        with torch.no_grad():
+            for p, s in zip(self.params, self.segments):
+                if not _dense(p):
+                    p.data = p.data.contiguous()
+                mview = torch.as_strided(self.master, p.shape, p.stride(), s.offset)
+                mview.copy_(p.data)
+                p.data = mview
+                p.grad = torch.as_strided(self.grad, p.shape, p.stride(), s.offset)
+                p._ddl_arena = self                                   # noqa: SLF001
+                p._ddl_segment = s.index                              # noqa: SLF001
+                if self.shadow is not None:
+                    p._ddl_shadow = torch.as_strided(self.shadow, p.shape, p.stride(), s.offset)  # noqa: SLF001
+        self._shadow_versions = [-1] * len(self.params)
+        self.sync_shadow()
+
+    # ------------------------------------------------------------------ views
+    def grad_range(self, lo: int, hi: int) -> torch.Tensor:
+        return self.grad[lo:hi]
+
+    def bucket_grad(self, b: int) -> torch.Tensor:
+        bk = self.buckets[b]
+        return self.grad[bk.lo:bk.hi]
+
+    def bucket_master(self, b: int) -> torch.Tensor:
+        bk = self.buckets[b]
+        return self.master[bk.lo:bk.hi]
+
+    def shard_range(self, b: int, rank: int, world: int):
+        """Element range of bucket ``b`` owned by ``rank`` in the PS / ZeRO-1 mode."""
+        bk = self.buckets[b]
+        n = (bk.hi - bk.lo) // world
+        return bk.lo + rank * n, bk.lo + (rank + 1) * n
+
+    # ------------------------------------------------------------------ maintenance
+    def zero_grad(self) -> None:
+        self.grad.zero_()
+
+    def reattach_grads(self) -> None:
+        """Re-point ``p.grad`` at the arena (after someone called ``zero_grad(set_to_none=True)``)."""
+        for p, s in zip(self.params, self.segments):
+            g = p.grad
+            if g is None or g.data_ptr() != self.grad.data_ptr() + 4 * s.offset:
+                view = torch.as_strided(self.grad, p.shape, p.stride(), s.offset)
+                if g is not None:
+                    view.copy_(g)
+                p.grad = view
+
+    def sync_shadow(self) -> None:
+        """Refresh the bf16 shadow from the fp32 master (after init, broadcast, load_state_dict, all-gather)."""
+        if self.shadow is not None:
+            if self.device.type == "cuda" and _lib.available():
+                from ..ops import kernels as K
+                K.cast_f32_bf16(self.master, self.shadow)
+            else:
+                self.shadow.copy_(self.master)
+        self.mark_shadow_current()
+
+    def mark_shadow_current(self) -> None:
+        for i, p in enumerate(self.params):
+            self._shadow_versions[i] = p._version
+            p._ddl_shadow_version = p._version                        # noqa: SLF001
+
+    def check_layout(self) -> None:
+        """Debug aid: every parameter / gradient must still alias the arena."""
+        for p, s in zip(self.params, self.segments):
+            if p.data_ptr() != self.master.data_ptr() + 4 * s.offset:
+                raise RuntimeError(f"parameter {s.name} no longer aliases the arena (was .data reassigned?)")
+
+    def describe(self) -> str:
+        mb = self.total * 4 / 2**20
+        return (f"ParamArena({len(self.params)} tensors, {self.total} elems = {mb:.1f} MiB fp32, "
+                f"{len(self.buckets)} buckets: " + ", ".join(f"{(b.hi - b.lo) * 4 / 2**20:.1f}" for b in self.buckets) + " MiB)")
+
+
+def _dense(p: torch.Tensor) -> bool:
+    """True when the tensor's strides describe a dense, non-overlapping layout (contiguous in some dim order)."""
+    if p.numel() == 0:
+        return True
+    dims = sorted(((st, sz) for st, sz in zip(p.stride(), p.shape) if sz > 1))
+    expect = 1
+    for st, sz in dims:
+        if st != expect:
+            return False
+        expect *= sz
+    return True
