@@ -100,7 +100,9 @@ class Trainer:
         cfg, info = self.cfg, self.info
         self.devices = self._devices()
         self.in_device, self.out_device = self.devices[0], self.devices[-1]
-        ddist.init(info, self.in_device, master_addr=cfg.master_addr, master_port=cfg.master_port)
+        external = info.launcher in ("torchrun", "mpi", "slurm") and "MASTER_PORT" in __import__("os").environ
+        ddist.init(info, self.in_device, master_addr=None if external else cfg.master_addr,
+                   master_port=None if external else cfg.master_port)
         torch.manual_seed(cfg.seed)                           # reference: torch.manual_seed(42), main.py:132
 
         model = models.build(cfg.model, **_model_kwargs(cfg))

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with `-m gpu` under gpurun)")
     config.addinivalue_line("markers", "dist: multi-process test (gloo on CPU)")
+    config.addinivalue_line("markers", "slow: large-model CPU test")
 
 
 def pytest_collection_modifyitems(config, items):

@@ -1,0 +1,188 @@
+"""Multi-process data-parallel tests on CPU / gloo — the same reducer logic that runs on RCCL."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn as tnn
+
+from _dist_util import run_ranks
+
+pytestmark = pytest.mark.dist
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _mlp(seed):
+    torch.manual_seed(seed)
+    return tnn.Sequential(tnn.Linear(12, 40), tnn.Tanh(), tnn.Linear(40, 24), tnn.Tanh(), tnn.Linear(24, 3))
+
+
+def _data(rank, n=8):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(n, 12, generator=g), torch.randn(n, 3, generator=g)
+
+
+# ---------------------------------------------------------------------------------------------
+def _grad_mean_worker(rank, world, mode, bucket_mb):
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena
+    m = _mlp(7 + rank)                                   # different init per rank: broadcast must fix it
+    arena = ParamArena(m.named_parameters(), bucket_bytes=int(bucket_mb * 2**20), shard_multiple=world)
+    ddp = DistributedDataParallel(m, mode=mode, arena=arena)
+    x, y = _data(rank)
+    ((ddp(x) - y) ** 2).mean().backward()
+    ddp.finish_grad_sync()
+    flat = ddp.arena.grad.clone()
+    rng = ddp.owned_ranges()
+    return {"grad": flat, "nb": len(ddp.arena.buckets), "ranges": rng,
+            "w0": ddp.arena.master.clone() if rank == 0 else None, "w": ddp.arena.master.clone()}
+
+
+@pytest.mark.parametrize("bucket_mb", [1e-3, 32.0])
+def test_bucketed_allreduce_equals_mean_of_rank_grads(bucket_mb):
+    out = run_ranks(_grad_mean_worker, 2, ("allreduce", bucket_mb))
+    assert torch.equal(out[0]["w"], out[1]["w"])                 # rank-0 broadcast (reference defect A6)
+    assert torch.equal(out[0]["grad"], out[1]["grad"])
+    if bucket_mb < 1:
+        assert out[0]["nb"] > 1
+    # single-process reference: mean of the two per-rank gradients with rank 0's weights
+    from distributed_deep_learning_amd.parallel import ParamArena
+    m = _mlp(7)
+    arena = ParamArena(m.named_parameters(), bucket_bytes=int(bucket_mb * 2**20), shard_multiple=2)
+    grads = []
+    for r in range(2):
+        arena.zero_grad()
+        x, y = _data(r)
+        ((m(x) - y) ** 2).mean().backward()
+        grads.append(arena.grad.clone())
+    assert torch.allclose(out[0]["grad"], (grads[0] + grads[1]) / 2, atol=1e-7)
+
+
+def test_ps_mode_reduces_owned_shards():
+    out = run_ranks(_grad_mean_worker, 2, ("ps", 1e-3))
+    ref = run_ranks(_grad_mean_worker, 2, ("allreduce", 1e-3))
+    for r in range(2):
+        for lo, hi in out[r]["ranges"]:
+            assert torch.allclose(out[r]["grad"][lo:hi], ref[r]["grad"][lo:hi], atol=1e-7)
+    covered = sorted(x for r in range(2) for x in out[r]["ranges"])
+    assert covered[0][0] == 0 and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
+# ---------------------------------------------------------------------------------------------
+def _train_worker(rank, world, mode, opt_kind, steps):
+    from distributed_deep_learning_amd.optim import LARS, FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    m = _mlp(3)
+    ddp = DistributedDataParallel(m, bucket_mb=2e-3, mode=mode)
+    if opt_kind == "lars":
+        opt = LARS(ddp.arena, lr=0.5, momentum=0.9, weight_decay=1e-3, eta=0.02)
+    else:
+        opt = FusedSGD(ddp.arena, lr=0.05, momentum=0.9, weight_decay=1e-3)
+    ddp.attach(opt)
+    for s in range(steps):
+        x, y = _data(rank * 1000 + s)
+        ((ddp(x) - y) ** 2).mean().backward()
+        ddp.step(opt)
+    cs = ddp.param_checksum()
+    return {"w": torch.cat([p.detach().flatten() for p in m.parameters()]), "checksum": cs, "names": ddp.arena.names}
+
+
+@pytest.mark.parametrize("opt_kind", ["sgd", "lars"])
+def test_replicas_identical_and_ps_equals_allreduce(opt_kind):
+    ar = run_ranks(_train_worker, 2, ("allreduce", opt_kind, 4))
+    ps = run_ranks(_train_worker, 2, ("ps", opt_kind, 4))
+    assert torch.equal(ar[0]["w"], ar[1]["w"])                   # replicas bit-identical after k steps
+    assert torch.equal(ps[0]["w"], ps[1]["w"])
+    assert torch.equal(ar[0]["checksum"][0], ar[0]["checksum"][1])
+    assert torch.allclose(ar[0]["w"], ps[0]["w"], atol=1e-6)     # PS mode == all-reduce mode
+    assert ar[0]["w"].abs().sum() > 0
+
+
+def _dp_vs_big_batch_worker(rank, world):
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    m = _mlp(5)
+    ddp = DistributedDataParallel(m)
+    opt = FusedSGD(ddp.arena, lr=0.1, momentum=0.9)
+    for s in range(3):
+        x, y = _data(10 * s + rank)
+        ((ddp(x) - y) ** 2).mean().backward()
+        ddp.step(opt)
+    return ddp.arena.master.clone()
+
+
+def test_dp_world2_equals_single_process_double_batch():
+    out = run_ranks(_dp_vs_big_batch_worker, 2)
+    from distributed_deep_learning_amd.optim import FusedSGD
+    m = _mlp(5)
+    opt = FusedSGD(m.named_parameters(), lr=0.1, momentum=0.9)
+    for s in range(3):
+        xs, ys = zip(*[_data(10 * s + r) for r in range(2)])
+        x, y = torch.cat(xs), torch.cat(ys)
+        ((m(x) - y) ** 2).mean().backward()
+        opt.step()
+    assert torch.allclose(out[0], opt.arena.master, atol=1e-6)
+
+
+def _no_sync_worker(rank, world):
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    m = _mlp(9)
+    ddp = DistributedDataParallel(m)
+    x, y = _data(rank)
+    with ddp.no_sync():
+        ((ddp(x) - y) ** 2).mean().backward()
+    local = ddp.arena.grad.clone()
+    ((ddp(x) - y) ** 2).mean().backward()               # second micro-batch: accumulate, then sync
+    ddp.finish_grad_sync()
+    return local, ddp.arena.grad.clone()
+
+
+def test_no_sync_accumulates_then_reduces():
+    out = run_ranks(_no_sync_worker, 2)
+    assert not torch.equal(out[0][0], out[1][0])                 # unsynced local grads differ
+    assert torch.equal(out[0][1], out[1][1])
+    assert torch.allclose(out[0][1], out[0][0] + out[1][0], atol=1e-6)   # mean of (2*g0, 2*g1)
+
+
+def _unused_param_worker(rank, world):
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    torch.manual_seed(0)
+    m = tnn.ModuleDict({"a": tnn.Linear(4, 4), "b": tnn.Linear(4, 4)})
+    ddp = DistributedDataParallel(m, bucket_mb=1e-4)
+    ddp._arm()
+    m["a"](torch.ones(2, 4) * (rank + 1)).sum().backward()      # "b" never gets a gradient
+    ddp.finish_grad_sync()                                      # must not deadlock
+    return ddp.arena.grad.clone()
+
+
+def test_unused_parameters_do_not_deadlock():
+    out = run_ranks(_unused_param_worker, 2)
+    assert torch.equal(out[0], out[1])
+
+
+# --------------------------------------------------------------------------------------------- launcher, end to end
+@pytest.mark.parametrize("extra", [[], ["--sync", "ps"]])
+def test_launcher_spawns_data_parallel_lenet(tmp_path, extra):
+    """North-star config 1: LeNet-5, MNIST-shape synthetic data, DP on CPU/gloo world_size=2."""
+    jl = os.path.join(tmp_path, "log.jsonl")
+    cmd = [sys.executable, "-m", "distributed_deep_learning_amd", "--model", "lenet5", "-m", "data", "-r", "2", "-e", "2",
+           "-b", "32", "--samples", "512", "--lr", "0.05", "--jsonl", jl, "--check-replicas", "2"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('"')]
+    assert len(lines) == 2 * 3 + 1                                # rank 0 only: 3 lines per epoch + test
+    assert lines[0].startswith('"train epoch 1 begins at ') and lines[-1].startswith('"test ends at ')
+    recs = [json.loads(l) for l in open(jl)]
+    ep = [x for x in recs if x["phase"] == "epoch"]
+    assert len(ep) == 2 and ep[1]["train_loss"] < ep[0]["train_loss"]
+
+
+def test_external_launcher_env_is_honoured(tmp_path):
+    """torchrun-style launch: ranks come from RANK/WORLD_SIZE, not from -r."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29611", "-m", "distributed_deep_learning_amd", "--model", "mlp", "-e", "1", "--samples", "256",
+           "--check-replicas", "1", "--global-metrics"]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert sum(1 for l in r.stdout.splitlines() if l.startswith('"test ends at ')) == 1
