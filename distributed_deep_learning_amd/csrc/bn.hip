@@ -7,6 +7,7 @@
 //                   running stats) -> apply  y = act(x*scale + shift [+ res])
 // backward        : reduce  (sum g, sum g*xhat with g = dy * [y > 0]) -> finalize (dgamma, dbeta, A, B, Cc)
 //                   -> apply dx = A*g + B*x + Cc  [dres = g]
+// The ReLU mask travels as 1 bit per element (written by the forward apply), so the backward never re-reads y.
 #include "common.h"
 #include "host_util.h"
 
@@ -76,19 +77,41 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
   }
 }
 
+// Fold the [nslots][2][C] slab for 64 channels per block: wave w sums slots w, w+4, ... (coalesced 256-byte rows),
+// the four partials meet in LDS.  Returns the two sums for channel c (valid in threads with threadIdx.x < 64).
+// The slab is SELF-CLEANING: every entry is zeroed right after it is read, so a slab that starts at zero (one
+// memset at allocation) can be reused by the next accumulate -> finalize pair without a memset launch.
+__device__ __forceinline__ void slab_fold(float* __restrict__ slab, int nslots, int C, float& s1, float& s2) {
+  __shared__ float part[4][2][64];
+  const int cc = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cc;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+#pragma unroll 4
+    for (int s = w; s < nslots; s += 4) {
+      float* p0 = slab + ((size_t)s * 2 + 0) * C + c;
+      float* p1 = slab + ((size_t)s * 2 + 1) * C + c;
+      a += *p0; b += *p1;
+      *p0 = 0.f; *p1 = 0.f;
+    }
+  }
+  part[w][0][cc] = a;
+  part[w][1][cc] = b;
+  __syncthreads();
+  s1 = part[0][0][cc] + part[1][0][cc] + part[2][0][cc] + part[3][0][cc];
+  s2 = part[0][1][cc] + part[1][1][cc] + part[2][1][cc] + part[3][1][cc];
+}
+
 // slab [nslots][2][C] -> mean/invstd/scale/shift (+ running stats, PyTorch semantics: unbiased running var)
-__global__ void bn_finalize_kernel(const float* __restrict__ slab, int nslots, int C, float count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ slab, int nslots, int C, float count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < nslots; ++s) {
-    s1 += slab[((size_t)s * 2 + 0) * C + c];
-    s2 += slab[((size_t)s * 2 + 1) * C + c];
-  }
+  float s1, s2;
+  slab_fold(slab, nslots, C, s1, s2);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= 64 || c >= C) return;
   const float mu = s1 / count;
   float var = s2 / count - mu * mu;
   var = fmaxf(var, 0.f);
@@ -108,7 +131,8 @@ __global__ void bn_finalize_kernel(const float* __restrict__ slab, int nslots, i
 // ---------------------------------------------------------------- forward: apply
 template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
-                                                       bf16_t* __restrict__ y, const float* __restrict__ scale,
+                                                       bf16_t* __restrict__ y, unsigned char* __restrict__ mask,
+                                                       const float* __restrict__ scale,
                                                        const float* __restrict__ shift, RowMap rm) {
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
@@ -132,6 +156,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
       for (int q = 0; q < 8; ++q) f[q] += r[q];
     }
     if (RELU) {
+      if (mask != nullptr) {                  // 1 bit per element: the backward reads this instead of y
+        unsigned m = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m |= (f[q] > 0.f ? 1u : 0u) << q;
+        mask[(size_t)row * rm.c8 + chunk] = (unsigned char)m;
+      }
 #pragma unroll
       for (int q = 0; q < 8; ++q) f[q] = fmaxf(f[q], 0.f);
     }
@@ -141,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
 
 // ---------------------------------------------------------------- backward: reductions
 template <bool RELU>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ slab,
                                                             RowMap rm) {
@@ -165,11 +195,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
       unpack8(gv, g);
       unpack8(xv, xf);
       if (RELU) {
-        const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
-        float yf[8];
-        unpack8(yv, yf);
+        const unsigned m = mask[(size_t)row * rm.c8 + chunk];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = yf[q] > 0.f ? g[q] : 0.f;
+        for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * (xf[q] - mu[q]) * is[q]; }
@@ -192,18 +220,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 }
 
 // slab -> dgamma, dbeta and the three per-channel coefficients of dx = A*g + B*x + Cc
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nslots, int C, float count,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ slab, int nslots, int C, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float sg = 0.f, sgx = 0.f;
-  for (int s = 0; s < nslots; ++s) {
-    sg += slab[((size_t)s * 2 + 0) * C + c];
-    sgx += slab[((size_t)s * 2 + 1) * C + c];
-  }
+  float sg, sgx;
+  slab_fold(slab, nslots, C, sg, sgx);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= 64 || c >= C) return;
   dgamma[c] = sgx;
   dbeta[c] = sg;
   const float g = gamma ? gamma[c] : 1.f;
@@ -215,7 +240,7 @@ __global__ void bn_bwd_finalize_kernel(const float* __restrict__ slab, int nslot
 }
 
 template <bool RELU, bool DRES>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
                                                            bf16_t* __restrict__ dres, const float* __restrict__ coefA,
                                                            const float* __restrict__ coefB,
@@ -235,11 +260,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     unpack8(gv, g);
     unpack8(xv, xf);
     if (RELU) {
-      const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
-      float yf[8];
-      unpack8(yv, yf);
+      const unsigned m = mask[(size_t)row * rm.c8 + chunk];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) g[q] = yf[q] > 0.f ? g[q] : 0.f;
+      for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
     }
     if (DRES) *reinterpret_cast<u32x4*>(dres + off) = pack8(g);
     float o[8];
@@ -252,57 +275,56 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 // ================================================================ C ABI
 extern "C" int ddl_bn_slots() { return BN_SLOTS; }
 
-// slab: [BN_SLOTS][2][C] fp32 workspace (zeroed here).
+// slab: [BN_SLOTS][2][C] fp32 workspace, must be ZERO on entry (finalize re-zeroes it: self-cleaning).
 extern "C" int ddl_bn_stats(const void* x, float* slab, int M, int C, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(slab, 0, sizeof(float) * BN_SLOTS * 2 * (size_t)C, st);
-  if (e != hipSuccess) return (int)e;
   const RowMap rm = make_rowmap(M, C);
   hipLaunchKernelGGL(bn_stats_kernel, rowmap_grid(rm), dim3(256), 0, st, (const bf16_t*)x, slab, rm);
   return (int)hipGetLastError();
 }
 
-extern "C" int ddl_bn_finalize(const float* slab, int nslots, int C, float count, const float* gamma,
+extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, float momentum,
                                float eps, float* mean, float* invstd, float* scale, float* shift, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, slab, nslots, C,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, nslots, C,
                      count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift);
   return (int)hipGetLastError();
 }
 
-extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, const float* scale, const float* shift, int M,
-                            int C, int relu, void* stream) {
+// mask (optional, only written when relu): [M][C/8] bytes, bit q of byte (row, chunk) = (y[row][chunk*8+q] > 0)
+extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
+                            const float* shift, int M, int C, int relu, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   const RowMap rm = make_rowmap(M, C);
   const dim3 grid = rowmap_grid(rm);
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* xp = (const bf16_t*)x; const bf16_t* rp = (const bf16_t*)res; bf16_t* yp = (bf16_t*)y;
+  unsigned char* mp = (unsigned char*)mask;
   if (res != nullptr) {
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
-    else      hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
   } else {
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
-    else      hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, st, xp, rp, yp, scale, shift, rm);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
   }
   return (int)hipGetLastError();
 }
 
-// Full backward.  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
-extern "C" int ddl_bn_backward(const void* dy, const void* y, const void* x, const float* gamma, const float* mean,
+// Full backward.  slab must be ZERO on entry (it is left zero again).  mask: the [M][C/8] ReLU bit mask written by ddl_bn_apply (required when relu).  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
+extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, const float* gamma, const float* mean,
                                const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
                                float* coef, int M, int C, int relu, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(slab, 0, sizeof(float) * BN_SLOTS * 2 * (size_t)C, st);
-  if (e != hipSuccess) return (int)e;
   const RowMap rm = make_rowmap(M, C);
   const dim3 grid = rowmap_grid(rm);
-  const bf16_t* dyp = (const bf16_t*)dy; const bf16_t* yp = (const bf16_t*)y; const bf16_t* xp = (const bf16_t*)x;
+  const bf16_t* dyp = (const bf16_t*)dy; const unsigned char* yp = (const unsigned char*)mask; const bf16_t* xp = (const bf16_t*)x;
+  if (relu && mask == nullptr) return -2;
   if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
   else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
   float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
                      mean, invstd, dgamma, dbeta, cA, cB, cC);
   bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
   if (relu) {

@@ -5,7 +5,10 @@
 // All tensors are NHWC bf16, accumulation is fp32 on the MFMA pipe (v_mfma_f32_16x16x32_bf16).
 //   MODE 0 (fwd)  : rows m = output pixels (n,p,q); ih = p*stride - pad + r.
 //   MODE 1 (dgrad): rows m = input pixels (n,h,w); the gathered tensor is dy, ih = (h + pad - r)/stride
-//                   when divisible; wmat is the [C][R][S][K] repack of the filter.
+//                   when divisible; wmat is the [C][R][S][K] repack of the filter.  For stride > 1 the launcher
+//                   splits the input pixels into stride^2 parity classes (h % stride, w % stride): inside a
+//                   class only the taps r = r0 + t*stride contribute and every one of them divides exactly, so
+//                   each class is a dense GEMM over its own tap subset (no MFMA work on structural zeros).
 //
 // Tile: BM pixels x BN out-channels x BK=64 reduction, 256 threads = 4 waves (2 x 2), each wave owns a
 // (BM/2) x (BN/2) sub-tile.  The weight tile is the MFMA A operand and the pixel tile the B operand, so every
@@ -27,6 +30,10 @@ struct ConvParams {
   int M, Kred;
   int tiles_m, tiles_n;
   int relu;
+  // row grid -> output pixel: (oh*o_step + o_ph, ow*o_step + o_pw) inside a [N][FOH][FOW] tensor
+  int o_step, o_ph, o_pw, FOH, FOW;
+  // tap subset: r = r0 + tr*t_step (tr < nR), s = s0 + ts*t_step (ts < nS); Kred = nR*nS*IC; KredFull = R*S*IC
+  int r0, s0, t_step, nR, nS, KredFull;
 };
 
 template <int BM, int BN, int MODE>
@@ -63,47 +70,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int ow = rem - oh * p.OW;
       nb[i] = n * p.IH * p.IW;
       if (MODE == 0) { bh[i] = oh * p.stride - p.pad; bw[i] = ow * p.stride - p.pad; }
-      else           { bh[i] = oh + p.pad;            bw[i] = ow + p.pad; }
+      else           { bh[i] = oh * p.o_step + p.o_ph + p.pad; bw[i] = ow * p.o_step + p.o_pw + p.pad; }
     } else {
       nb[i] = 0; bh[i] = -(1 << 28); bw[i] = -(1 << 28);
     }
   }
-  // ---- per-thread reduction cursor: kk = k0 + chunk*8 -> (r, s, c) ----
+  // ---- per-thread reduction cursor: kk = k0 + chunk*8 -> (tap row, tap col, c) inside the tap subset ----
   int kr, ks_, kc;
   {
     const int kk = chunk * 8;
     const int tap = kk / p.IC;
     kc = kk - tap * p.IC;
-    kr = tap / p.S;
-    ks_ = tap - kr * p.S;
+    kr = tap / p.nS;
+    ks_ = tap - kr * p.nS;
   }
-  int kkw = chunk * 8;
 
   u32x4 xr[XI], wr[WI];
 
   auto load_tile = [&]() {
+    const int r = p.r0 + kr * p.t_step, sx = p.s0 + ks_ * p.t_step;   // actual filter tap of this chunk
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
       int ih, iw; bool ok;
       if (MODE == 0) {
-        ih = bh[i] + kr; iw = bw[i] + ks_;
+        ih = bh[i] + r; iw = bw[i] + sx;
         ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
       } else {
-        const int th = bh[i] - kr, tw = bw[i] - ks_;
-        if (p.stride == 1) {
-          ih = th; iw = tw;
-          ok = ((unsigned)th < (unsigned)p.IH) && ((unsigned)tw < (unsigned)p.IW);
-        } else if (p.stride == 2) {
-          ok = (th >= 0) && (tw >= 0) && (((th | tw) & 1) == 0);
-          ih = th >> 1; iw = tw >> 1;
-          ok = ok && (ih < p.IH) && (iw < p.IW);
-        } else {
-          ok = (th >= 0) && (tw >= 0);
-          ih = th / p.stride; iw = tw / p.stride;
-          ok = ok && (ih * p.stride == th) && (iw * p.stride == tw) && (ih < p.IH) && (iw < p.IW);
-        }
+        const int th = bh[i] - r, tw = bw[i] - sx;          // multiples of stride by construction of the class
+        if (p.stride == 1)      { ih = th; iw = tw; }
+        else if (p.stride == 2) { ih = th >> 1; iw = tw >> 1; }
+        else                    { ih = th / p.stride; iw = tw / p.stride; }
+        ok = (th >= 0) && (tw >= 0) && (ih < p.IH) && (iw < p.IW);
       }
-      ok = ok && (kr < p.R);
+      ok = ok && (kr < p.nR);
       u32x4 v = {0u, 0u, 0u, 0u};
       if (ok) {
         const size_t off = ((size_t)(nb[i] + ih * p.IW + iw)) * (size_t)p.IC + (size_t)kc;
@@ -115,18 +114,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int i = 0; i < WI; ++i) {
       const int n = n0 + row0 + 32 * i;
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < p.OC && kkw < p.Kred) {
-        v = *reinterpret_cast<const u32x4*>(p.wmat + (size_t)n * (size_t)p.Kred + (size_t)kkw);
+      if (n < p.OC && kr < p.nR) {
+        const int woff = (r * p.S + sx) * p.IC + kc;
+        v = *reinterpret_cast<const u32x4*>(p.wmat + (size_t)n * (size_t)p.KredFull + (size_t)woff);
       }
       wr[i] = v;
     }
   };
   auto advance = [&]() {
-    kkw += 64;
     kc += 64;
     while (kc >= p.IC) {
       kc -= p.IC;
-      if (++ks_ == p.S) { ks_ = 0; ++kr; }
+      if (++ks_ == p.nS) { ks_ = 0; ++kr; }
     }
   };
   auto store_tile = [&](int buf) {
@@ -228,7 +227,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int m = m0 + row;
     const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * OPITCH + oc * 16);
     if (m < p.M && ncol < p.OC) {
-      *reinterpret_cast<u32x4*>(p.out + (size_t)m * (size_t)p.OC + (size_t)ncol) = v;
+      size_t opix = (size_t)m;
+      if (p.o_step != 1) {                       // parity-class sub-grid -> pixel of the full output tensor
+        const int ohw = p.OH * p.OW;
+        const int n = m / ohw;
+        const int rem = m - n * ohw;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
+      }
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = v;
       if (p.stats != nullptr) {
         float f[8];
         unpack8(v, f);
@@ -269,29 +277,66 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 }
 
 // mode: 0 = forward gather, 1 = dgrad gather.  Returns a hipError_t code (0 = ok), or negative for bad arguments.
-// `stats`, when not null, must hold DDL_BN_SLOTS * 2 * OC floats (it is zeroed here, then accumulated).
+// `stats`, when not null, must hold DDL_BN_SLOTS * 2 * OC floats and be ZERO on entry (partials are accumulated
+// with atomics; ddl_bn_finalize folds the slab and leaves it zero again).
+
+template <int MODE>
+static int launch_any(ConvParams& p, hipStream_t st) {
+  p.tiles_m = (p.M + 127) / 128;
+  if (p.OC <= 64) {
+    p.tiles_n = (p.OC + 63) / 64;
+    return launch_conv<128, 64, MODE>(p, st);
+  }
+  p.tiles_n = (p.OC + 127) / 128;
+  return launch_conv<128, 128, MODE>(p, st);
+}
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
                               int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
-  if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0) return -2;
+  if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
   const long long M = (long long)N * OH * OW;
   if (M >= (1ll << 31) || (long long)N * IH * IW >= (1ll << 31)) return -3;
   ConvParams p;
   p.in = (const bf16_t*)in; p.wmat = (const bf16_t*)wmat; p.out = (bf16_t*)out; p.bias = bias; p.stats = stats;
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
-  p.stride = stride; p.pad = pad; p.M = (int)M; p.Kred = R * S * IC; p.relu = relu;
-  p.tiles_m = ((int)M + 127) / 128;
+  p.stride = stride; p.pad = pad; p.relu = relu;
+  p.KredFull = R * S * IC;
+  p.FOH = OH; p.FOW = OW;
   hipStream_t st = (hipStream_t)stream;
-  if (stats != nullptr) {
-    hipError_t e = hipMemsetAsync(stats, 0, sizeof(float) * DDL_BN_SLOTS * 2 * (size_t)OC, st);
+  if (mode == 0 || stride == 1) {
+    p.M = (int)M; p.Kred = p.KredFull;
+    p.o_step = 1; p.o_ph = 0; p.o_pw = 0;
+    p.r0 = 0; p.s0 = 0; p.t_step = 1; p.nR = R; p.nS = S;
+    return mode == 0 ? launch_any<0>(p, st) : launch_any<1>(p, st);
+  }
+  // dgrad with stride > 1: one dense launch per parity class of the input pixels
+  bool any_empty = false;
+  for (int ph = 0; ph < stride && !any_empty; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      const int r0 = (ph + pad) % stride, s0 = (pw + pad) % stride;
+      if (r0 >= R || s0 >= S || ph >= OH || pw >= OW) { any_empty = true; break; }
+    }
+  if (any_empty) {   // classes without a contributing tap (e.g. 1x1 stride-2) are plain zeros
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(bf16_t) * (size_t)M * (size_t)OC, st);
     if (e != hipSuccess) return (int)e;
   }
-  if (OC <= 64) {
-    p.tiles_n = (OC + 63) / 64;
-    return mode == 0 ? launch_conv<128, 64, 0>(p, st) : launch_conv<128, 64, 1>(p, st);
-  }
-  p.tiles_n = (OC + 127) / 128;
-  return mode == 0 ? launch_conv<128, 128, 0>(p, st) : launch_conv<128, 128, 1>(p, st);
+  for (int ph = 0; ph < stride; ++ph)
+    for (int pw = 0; pw < stride; ++pw) {
+      const int r0 = (ph + pad) % stride, s0 = (pw + pad) % stride;
+      if (r0 >= R || s0 >= S || ph >= OH || pw >= OW) continue;
+      ConvParams q = p;
+      q.OH = (OH - ph + stride - 1) / stride;
+      q.OW = (OW - pw + stride - 1) / stride;
+      q.M = N * q.OH * q.OW;
+      q.o_step = stride; q.o_ph = ph; q.o_pw = pw;
+      q.r0 = r0; q.s0 = s0; q.t_step = stride;
+      q.nR = (R - r0 + stride - 1) / stride;
+      q.nS = (S - s0 + stride - 1) / stride;
+      q.Kred = q.nR * q.nS * IC;
+      const int rc = launch_any<1>(q, st);
+      if (rc != 0) return rc;
+    }
+  return 0;
 }

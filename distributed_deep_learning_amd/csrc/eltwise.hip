@@ -130,6 +130,47 @@ __global__ __launch_bounds__(256) void filter_repack_kernel(const TIN* __restric
   }
 }
 
+// All conv filters of an arena in ONE launch: bf16 shadow [K][RS][C] at in_off -> [C][RS][K] at out_off.
+struct RepackDesc {
+  long long in_off, out_off;
+  int K, RS, C, tile_begin, tiles_c, tiles_k;
+};
+
+__global__ __launch_bounds__(256) void filter_transpose_batched_kernel(const bf16_t* __restrict__ src,
+                                                                       bf16_t* __restrict__ dst,
+                                                                       const RepackDesc* __restrict__ descs,
+                                                                       int ndesc) {
+  __shared__ bf16_t tile[32][33];
+  int lo = 0, hi = ndesc - 1;                 // last descriptor with tile_begin <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (descs[mid].tile_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const RepackDesc d = descs[lo];
+  int local = blockIdx.x - d.tile_begin;
+  const int per_tap = d.tiles_c * d.tiles_k;
+  const int tap = local / per_tap;
+  local -= tap * per_tap;
+  const int tk = local / d.tiles_c, tc = local - tk * d.tiles_c;
+  const int c0 = tc * 32, k0 = tk * 32;
+  const bf16_t* in = src + d.in_off;
+  bf16_t* out = dst + d.out_off;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty + i * 8, c = c0 + tx;
+    bf16_t v = 0;
+    if (k < d.K && c < d.C) v = in[((size_t)k * d.RS + tap) * d.C + c];
+    tile[ty + i * 8][tx] = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, k = k0 + tx;
+    if (c < d.C && k < d.K) out[((size_t)c * d.RS + tap) * d.K + k] = tile[tx][ty + i * 8];
+  }
+}
+
 // NCHW fp32 -> NHWC bf16 with the channel axis zero-padded to Cp (input images: 3 -> 8)
 __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
                                                                int N, int C, int HW, int Cp, long long total) {
@@ -207,6 +248,15 @@ extern "C" int ddl_filter_repack(const void* in, int in_is_f32, void* copy, void
                        (bf16_t*)copy, (bf16_t*)outT, K, RS, C);
   return (int)hipGetLastError();
 }
+// descs: device array of RepackDesc (48 bytes each, see ops/kernels.py), total_tiles = sum RS*tiles_c*tiles_k
+extern "C" int ddl_filter_transpose_batched(const void* src, void* dst, const void* descs, int ndesc, int total_tiles,
+                                            void* stream) {
+  if (ndesc <= 0 || total_tiles <= 0) return 0;
+  hipLaunchKernelGGL(filter_transpose_batched_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (bf16_t*)dst, (const RepackDesc*)descs, ndesc);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_repack_desc_bytes() { return (int)sizeof(RepackDesc); }
 extern "C" int ddl_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, int HW, int Cp, void* stream) {
   if (Cp % 8 != 0 || Cp < C) return -1;
   const long long total = (long long)N * HW * (Cp / 8);

@@ -20,36 +20,51 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == BF16 else t.to(BF16)
 
 
+def _wgrad(weight, dy, x, R, S, stride, pad, cin_real):
+    """Filter gradient.  When the parameter's ``.grad`` is a view of a flat arena, the split-K atomics of the wgrad
+    kernel accumulate STRAIGHT into it (no temporary, no zero-fill, no autograd add) and ``None`` is returned to
+    autograd; the arena then tells the data-parallel reducer that this tensor's gradient is ready."""
+    arena = getattr(weight, "_ddl_arena", None)
+    if arena is not None and cin_real == x.shape[1] and arena.grad_is_arena_view(weight):
+        K.conv2d_wgrad(dy, x, R, S, stride, pad, out=weight.grad)
+        arena.notify_grad_ready(weight)
+        return None
+    dw = K.conv2d_wgrad(dy, x, R, S, stride, pad)
+    if cin_real != dw.shape[1]:
+        dw = dw[:, :cin_real]
+    return dw
+
+
 class ConvBNAct(torch.autograd.Function):
     """y = act(BN_train(conv(x, w)) [+ residual]) with BN statistics fused into the conv epilogue."""
 
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, w_krsc, w_crsk, running_mean, running_var, momentum, eps,
-                stride, pad, relu, cin_real):
+                stride, pad, relu, cin_real, slabs):
         x = K.nhwc(_bf16(x))
-        y_conv, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True)
+        y_conv, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True, slab=slabs[0] if slabs else None)
         N, _, P, Q = y_conv.shape
         vec = K.bn_finalize(stats, N * P * Q, gamma, beta, running_mean, running_var, momentum, eps)
         res = K.nhwc(_bf16(residual)) if residual is not None else None
-        out = K.bn_apply(y_conv, vec[2], vec[3], residual=res, relu=relu)
-        ctx.save_for_backward(x, y_conv, out, vec, gamma, w_crsk)
+        out, mask = K.bn_apply(y_conv, vec[2], vec[3], residual=res, relu=relu, want_mask=True)
+        ctx.save_for_backward(x, y_conv, mask, vec, gamma, w_crsk)
         ctx.geom = (stride, pad, relu, residual is not None, w_krsc.shape[1], w_krsc.shape[2], cin_real)
+        ctx.weight = weight
+        ctx.slab = slabs[1] if slabs else None
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, y_conv, out, vec, gamma, w_crsk = ctx.saved_tensors
+        x, y_conv, mask, vec, gamma, w_crsk = ctx.saved_tensors
         stride, pad, relu, has_res, R, S, cin_real = ctx.geom
         dout = K.nhwc(_bf16(dout))
-        dconv, dres, dgamma, dbeta = K.bn_backward(dout, out, y_conv, gamma, vec[0], vec[1], relu=relu,
-                                                   want_dres=has_res)
+        dconv, dres, dgamma, dbeta = K.bn_backward(dout, mask, y_conv, gamma, vec[0], vec[1], relu=relu,
+                                                   want_dres=has_res, slab=ctx.slab)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dconv, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = K.conv2d_wgrad(dconv, x, R, S, stride, pad)
-        if cin_real != dw.shape[1]:
-            dw = dw[:, :cin_real]
-        return (dx, dw, dgamma, dbeta, dres) + (None,) * 10
+        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
+        return (dx, dw, dgamma, dbeta, dres) + (None,) * 11
 
 
 class ConvBiasAct(torch.autograd.Function):
@@ -61,6 +76,7 @@ class ConvBiasAct(torch.autograd.Function):
         y, _ = K.conv2d_fwd(x, w_krsc, stride, pad, bias=bias, relu=relu)
         ctx.save_for_backward(x, y if relu else None, w_crsk)
         ctx.geom = (stride, pad, relu, bias is not None, w_krsc.shape[1], w_krsc.shape[2], cin_real)
+        ctx.weight = weight
         return y
 
     @staticmethod
@@ -74,9 +90,7 @@ class ConvBiasAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = K.conv2d_wgrad(dy, x, R, S, stride, pad)
-        if cin_real != dw.shape[1]:
-            dw = dw[:, :cin_real]
+        dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real)
         return (dx, dw, db) + (None,) * 6
 
 
@@ -84,24 +98,26 @@ class BNAct(torch.autograd.Function):
     """Stand-alone training BatchNorm (+ residual)(+ ReLU) for inputs not produced by our conv (e.g. concat)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu):
+    def forward(ctx, x, gamma, beta, residual, running_mean, running_var, momentum, eps, relu, slabs):
         x = K.nhwc(_bf16(x))
         N, _, H, W = x.shape
-        slab = K.bn_stats(x)
+        slab = K.bn_stats(x, slab=slabs[0] if slabs else None)
+        ctx.slab = slabs[1] if slabs else None
         vec = K.bn_finalize(slab, N * H * W, gamma, beta, running_mean, running_var, momentum, eps)
         res = K.nhwc(_bf16(residual)) if residual is not None else None
-        out = K.bn_apply(x, vec[2], vec[3], residual=res, relu=relu)
-        ctx.save_for_backward(x, out, vec, gamma)
+        out, mask = K.bn_apply(x, vec[2], vec[3], residual=res, relu=relu, want_mask=True)
+        ctx.save_for_backward(x, mask, vec, gamma)
         ctx.flags = (relu, residual is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, out, vec, gamma = ctx.saved_tensors
+        x, mask, vec, gamma = ctx.saved_tensors
         relu, has_res = ctx.flags
         dout = K.nhwc(_bf16(dout))
-        dx, dres, dgamma, dbeta = K.bn_backward(dout, out, x, gamma, vec[0], vec[1], relu=relu, want_dres=has_res)
-        return (dx, dgamma, dbeta, dres) + (None,) * 5
+        dx, dres, dgamma, dbeta = K.bn_backward(dout, mask, x, gamma, vec[0], vec[1], relu=relu, want_dres=has_res,
+                                                slab=ctx.slab)
+        return (dx, dgamma, dbeta, dres) + (None,) * 6
 
 
 class AffineAct(torch.autograd.Function):

@@ -64,6 +64,10 @@ class Conv2d(tnn.Conv2d):
     def packed(self):
         """(bf16 KRSC, bf16 CRSK) with input channels zero-padded to a multiple of 8."""
         w = self.weight
+        sh_t = getattr(w, "_ddl_shadow_t", None)
+        if sh_t is not None and getattr(w, "_ddl_shadow_version", -1) == w._version:
+            # arena-resident bf16 shadow + CRSK twin, kept current by the fused optimizer: nothing to launch
+            return w._ddl_shadow.permute(0, 2, 3, 1), sh_t
         key = (w._version, _state.weights_epoch(), w.data_ptr(), w.device)
         if self._pack is not None and self._pack[0] == key:
             return self._pack[1], self._pack[2]
@@ -102,7 +106,37 @@ class Conv2d(tnn.Conv2d):
 
 
 class BatchNorm2d(tnn.BatchNorm2d):
-    """BatchNorm with optional fused residual add and ReLU: ``bn(x, residual=None, relu=False)``."""
+    """BatchNorm with optional fused residual add and ReLU: ``bn(x, residual=None, relu=False)``.
+
+    GPU training keeps two persistent self-cleaning reduction slabs per layer (forward statistics, backward
+    sums) and counts ``num_batches_tracked`` on the host, folding it into the buffer when the state is saved —
+    no per-step memsets or counter kernels."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._slabs = None
+        self._nbt_pending = 0
+
+    def slabs(self, device):
+        if self._slabs is None or self._slabs[0].device != device:
+            self._slabs = (K.new_slab(self.num_features, device), K.new_slab(self.num_features, device))
+        return self._slabs
+
+    def _count_batch(self) -> None:
+        self._nbt_pending += 1
+
+    def flush_counters(self) -> None:
+        if self._nbt_pending and self.num_batches_tracked is not None:
+            self.num_batches_tracked += self._nbt_pending
+        self._nbt_pending = 0
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        self.flush_counters()
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._nbt_pending = 0
+        super()._load_from_state_dict(*args, **kwargs)
 
     def _eval_affine(self):
         with torch.no_grad():
@@ -114,8 +148,8 @@ class BatchNorm2d(tnn.BatchNorm2d):
         return scale, shift
 
     def _momentum(self) -> float:
-        if self.momentum is None:
-            return 1.0 / float(self.num_batches_tracked.item() + 1)
+        if self.momentum is None:      # cumulative moving average (called after _count_batch)
+            return 1.0 / float(self.num_batches_tracked.item() + self._nbt_pending)
         return self.momentum
 
     def forward(self, x, residual=None, relu: bool = False):
@@ -129,11 +163,11 @@ class BatchNorm2d(tnn.BatchNorm2d):
             return y.to(BF16).contiguous(memory_format=CL) if x.is_cuda else y
         if use_batch_stats:
             if self.training and self.track_running_stats:
-                self.num_batches_tracked += 1
+                self._count_batch()
             return F.BNAct.apply(x, self.weight, self.bias, residual,
                                  self.running_mean if self.track_running_stats else None,
                                  self.running_var if self.track_running_stats else None,
-                                 self._momentum(), self.eps, relu)
+                                 self._momentum(), self.eps, relu, self.slabs(x.device))
         scale, shift = self._eval_affine()
         return F.AffineAct.apply(x, scale, shift, residual, relu)
 
@@ -146,10 +180,10 @@ def conv_bn_act(conv: Conv2d, bn: BatchNorm2d, x, relu: bool = True, residual=No
         if x.shape[1] != _pad8(conv.in_channels):
             x = to_device_input(x)
         krsc, crsk = conv.packed()
-        bn.num_batches_tracked += 1
+        bn._count_batch()
         return F.ConvBNAct.apply(x, conv.weight, bn.weight, bn.bias, residual, krsc, crsk, bn.running_mean,
                                  bn.running_var, bn._momentum(), bn.eps, conv.stride[0], conv.padding[0], relu,
-                                 conv.in_channels)
+                                 conv.in_channels, bn.slabs(x.device))
     return bn(conv(x), residual=residual, relu=relu)
 
 

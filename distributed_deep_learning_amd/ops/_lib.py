@@ -28,7 +28,7 @@ _SIGS = {
     "ddl_bn_slots": [],
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
     "ddl_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
-    "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _vp],
     "ddl_maxpool_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
     "ddl_maxpool_bwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
@@ -43,6 +43,8 @@ _SIGS = {
     "ddl_add": [_vp, _vp, _vp, _ll, _i, _vp],
     "ddl_bias_grad": [_vp, _vp, _i, _i, _vp],
     "ddl_filter_repack": [_vp, _i, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_filter_transpose_batched": [_vp, _vp, _vp, _i, _i, _vp],
+    "ddl_repack_desc_bytes": [],
     "ddl_nchw_to_nhwc_pad": [_vp, _vp, _i, _i, _i, _i, _vp],
     "ddl_softmax_xent": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "ddl_chunk_elems": [],

@@ -54,8 +54,15 @@ def filter_repack(w: torch.Tensor, want_copy: bool = True):
     return copy, wT
 
 
-def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=False):
-    """x: bf16 NHWC activations; w_krsc: bf16 ``[K,R,S,C]`` contiguous.  Returns ``(y, stats_slab or None)``."""
+def new_slab(channels: int, device) -> torch.Tensor:
+    """A zeroed ``[slots, 2, C]`` reduction slab.  Slabs are self-cleaning (the finalize kernels re-zero them), so
+    one can be kept per layer and reused every step without a memset."""
+    return torch.zeros((_lib.bn_slots(), 2, channels), dtype=torch.float32, device=device)
+
+
+def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=False, slab=None):
+    """x: bf16 NHWC activations; w_krsc: bf16 ``[K,R,S,C]`` contiguous.  Returns ``(y, stats_slab or None)``.
+    ``slab``: optional zeroed workspace from :func:`new_slab` to accumulate the BN partial sums into."""
     lib = _lib.require()
     _chk_act(x, "conv2d_fwd")
     x = nhwc(x)
@@ -69,7 +76,7 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     if P <= 0 or Q <= 0:
         raise ValueError("conv2d_fwd: empty output")
     y = torch.empty((N, K, P, Q), dtype=BF16, device=x.device, memory_format=CL)
-    stats = torch.empty((_lib.bn_slots(), 2, K), dtype=torch.float32, device=x.device) if want_stats else None
+    stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
         raise TypeError("conv2d_fwd: bias must be fp32 [K]")
     check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), N, P, Q, H, W, Cc, K, R, S,
@@ -95,8 +102,9 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0):
     return dx
 
 
-def conv2d_wgrad(dy, x, R, S, stride=1, pad=0):
-    """Returns dw as an fp32 tensor of logical shape ``[K,C,R,S]`` with channels-last (KRSC) strides."""
+def conv2d_wgrad(dy, x, R, S, stride=1, pad=0, out=None):
+    """Returns dw as an fp32 tensor of logical shape ``[K,C,R,S]`` with channels-last (KRSC) strides.
+    ``out``: optional fp32 ``[K,C,R,S]`` channels-last tensor to ACCUMULATE into (e.g. the arena gradient view)."""
     lib = _lib.require()
     _chk_act(dy, "conv2d_wgrad")
     _chk_act(x, "conv2d_wgrad")
@@ -105,6 +113,13 @@ def conv2d_wgrad(dy, x, R, S, stride=1, pad=0):
     N2, Cc, H, W = x.shape
     if N2 != N or conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
         raise ValueError("conv2d_wgrad: geometry mismatch")
+    if out is not None:
+        if (out.dtype != torch.float32 or tuple(out.shape) != (K, Cc, R, S)
+                or not out.permute(0, 2, 3, 1).is_contiguous()):
+            raise ValueError("conv2d_wgrad: out must be fp32 [K,C,R,S] with channels-last (KRSC) strides")
+        check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(out), N, H, W, Cc, K, P, Q, R, S, stride, pad, stream_ptr()),
+              "conv2d_wgrad")
+        return out
     dw = torch.zeros((K, R, S, Cc), dtype=torch.float32, device=x.device)
     check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(dw), N, H, W, Cc, K, P, Q, R, S, stride, pad, stream_ptr()),
           "conv2d_wgrad")
@@ -112,12 +127,13 @@ def conv2d_wgrad(dy, x, R, S, stride=1, pad=0):
 
 
 # ----------------------------------------------------------------------------------------------- batch norm
-def bn_stats(x):
+def bn_stats(x, slab=None):
     lib = _lib.require()
     _chk_act(x, "bn_stats")
     x = nhwc(x)
     N, Cc, H, W = x.shape
-    slab = torch.empty((_lib.bn_slots(), 2, Cc), dtype=torch.float32, device=x.device)
+    if slab is None:
+        slab = new_slab(Cc, x.device)
     check(lib.ddl_bn_stats(ptr(x), ptr(slab), N * H * W, Cc, stream_ptr()), "bn_stats")
     return slab
 
@@ -133,7 +149,9 @@ def bn_finalize(slab, count, gamma, beta, running_mean, running_var, momentum, e
     return vec
 
 
-def bn_apply(x, scale, shift, residual=None, relu=True):
+def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False):
+    """y = act(x*scale + shift [+ residual]).  With ``want_mask`` also returns the 1-bit-per-element ReLU mask
+    (``uint8 [N*H*W, C/8]``) that :func:`bn_backward` consumes instead of re-reading ``y``."""
     lib = _lib.require()
     _chk_act(x, "bn_apply")
     x = nhwc(x)
@@ -144,25 +162,27 @@ def bn_apply(x, scale, shift, residual=None, relu=True):
         if residual.shape != x.shape:
             raise ValueError("bn_apply: residual shape mismatch")
     y = torch.empty_like(x, memory_format=CL)
-    check(lib.ddl_bn_apply(ptr(x), ptr(residual), ptr(y), ptr(scale), ptr(shift), N * H * W, Cc, int(relu),
+    mask = torch.empty((N * H * W, Cc // 8), dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
+    check(lib.ddl_bn_apply(ptr(x), ptr(residual), ptr(y), ptr(mask), ptr(scale), ptr(shift), N * H * W, Cc, int(relu),
                            stream_ptr()), "bn_apply")
-    return y
+    return (y, mask) if want_mask else y
 
 
-def bn_backward(dy, y, x, gamma, mean, invstd, relu=True, want_dres=False):
-    """Returns ``(dx, dres or None, dgamma, dbeta)``; ``y`` (the forward output) is only read when ``relu``."""
+def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, slab=None):
+    """Returns ``(dx, dres or None, dgamma, dbeta)``; ``mask`` is the bit mask from :func:`bn_apply` (``relu`` only)."""
     lib = _lib.require()
     _chk_act(dy, "bn_backward")
     dy, x = nhwc(dy), nhwc(x)
-    if relu:
-        y = nhwc(y)
     N, Cc, H, W = x.shape
+    if relu and (mask is None or mask.dtype != torch.uint8 or mask.numel() != N * H * W * Cc // 8):
+        raise ValueError("bn_backward: relu=True needs the uint8 [N*H*W, C/8] mask from bn_apply(want_mask=True)")
     dx = torch.empty_like(x, memory_format=CL)
     dres = torch.empty_like(x, memory_format=CL) if want_dres else None
     dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
-    work = torch.empty((_lib.bn_slots() * 2 + 3, Cc), dtype=torch.float32, device=x.device)
-    slab, coef = work[: _lib.bn_slots() * 2], work[_lib.bn_slots() * 2:]
-    check(lib.ddl_bn_backward(ptr(dy), ptr(y) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
+    if slab is None:
+        slab = new_slab(Cc, x.device)
+    coef = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
+    check(lib.ddl_bn_backward(ptr(dy), ptr(mask) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
                               stream_ptr()), "bn_backward")
     return dx, dres, dgb[0], dgb[1]
@@ -231,6 +251,13 @@ def gap_bwd(dy, in_hw):
     dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
     check(lib.ddl_gap_bwd(ptr(dy), ptr(dx), N, H * W, Cc, stream_ptr()), "gap_bwd")
     return dx
+
+
+def filter_transpose_batched(src: torch.Tensor, dst: torch.Tensor, descs: torch.Tensor, ndesc: int, total_tiles: int):
+    """One launch for every conv filter of an arena: bf16 KRSC shadow -> bf16 CRSK (see ParamArena)."""
+    lib = _lib.require()
+    check(lib.ddl_filter_transpose_batched(ptr(src), ptr(dst), ptr(descs), ndesc, total_tiles, stream_ptr()),
+          "filter_transpose_batched")
 
 
 # ----------------------------------------------------------------------------------------------- element-wise

@@ -112,6 +112,7 @@ class _ArenaOptimizer(torch.optim.Optimizer):
                 self._update(clo, chi, zero_grad)
         _state.bump()
         if self.arena.shadow is not None and self._use_kernel():
+            self.arena.refresh_transposes()
             self.arena.mark_shadow_current()
         return loss
 

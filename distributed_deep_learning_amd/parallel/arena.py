@@ -129,7 +129,55 @@ class ParamArena:
                 if self.shadow is not None:
                     p._ddl_shadow = torch.as_strided(self.shadow, p.shape, p.stride(), s.offset)  # noqa: SLF001
         self._shadow_versions = [-1] * len(self.params)
+        self.on_grad_ready = None          # set by the DP reducer: called with a segment index
+        self.shadow_t = None               # bf16 [C][R][S][K] repacks of every conv filter (dgrad operand)
+        self._repack = None
+        if self.shadow is not None and dev.type == "cuda":
+            self._build_repack_table()
         self.sync_shadow()
+
+    # ------------------------------------------------------------------ conv filter repacks (one launch per step)
+    def _build_repack_table(self) -> None:
+        """Descriptor table for ``csrc/eltwise.hip::filter_transpose_batched_kernel``: every 4-D parameter stored
+        channels-last (physically KRSC) with C % 8 == 0 and K % 8 == 0 gets a CRSK twin at the same arena offset."""
+        import numpy as np
+        dt = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("K", "<i4"), ("RS", "<i4"), ("C", "<i4"),
+                       ("tile_begin", "<i4"), ("tiles_c", "<i4"), ("tiles_k", "<i4")])
+        rows, tile = [], 0
+        for p, s in zip(self.params, self.segments):
+            if p.dim() != 4 or p.shape[1] % 8 or p.shape[0] % 8 or not p.permute(0, 2, 3, 1).is_contiguous():
+                continue
+            K_, C_, R_, S_ = p.shape
+            tc, tk = (C_ + 31) // 32, (K_ + 31) // 32
+            rows.append((s.offset, s.offset, K_, R_ * S_, C_, tile, tc, tk))
+            tile += R_ * S_ * tc * tk
+        if not rows:
+            return
+        assert dt.itemsize == _lib.require().ddl_repack_desc_bytes()
+        arr = np.array(rows, dtype=dt)
+        self.shadow_t = torch.zeros(self.total, dtype=torch.bfloat16, device=self.device)
+        descs = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
+        self._repack = (descs, len(rows), tile)
+        for p, s in zip(self.params, self.segments):
+            if p.dim() == 4 and not (p.shape[1] % 8 or p.shape[0] % 8) and p.permute(0, 2, 3, 1).is_contiguous():
+                K_, C_, R_, S_ = p.shape
+                p._ddl_shadow_t = self.shadow_t[s.offset:s.offset + s.numel].view(C_, R_, S_, K_)   # noqa: SLF001
+
+    def refresh_transposes(self) -> None:
+        if self._repack is not None:
+            from ..ops import kernels as K
+            descs, n, tiles = self._repack
+            K.filter_transpose_batched(self.shadow, self.shadow_t, descs, n, tiles)
+
+    def notify_grad_ready(self, p) -> None:
+        """Called by kernels that accumulate straight into the arena gradient (bypassing autograd's
+        AccumulateGrad, so its hooks do not fire)."""
+        if self.on_grad_ready is not None:
+            self.on_grad_ready(p._ddl_segment)                        # noqa: SLF001
+
+    def grad_is_arena_view(self, p) -> bool:
+        g = p.grad
+        return g is not None and g.data_ptr() == self.grad.data_ptr() + 4 * self.segments[p._ddl_segment].offset  # noqa: SLF001
 
     # ------------------------------------------------------------------ views
     def grad_range(self, lo: int, hi: int) -> torch.Tensor:
@@ -171,6 +219,7 @@ class ParamArena:
                 K.cast_f32_bf16(self.master, self.shadow)
             else:
                 self.shadow.copy_(self.master)
+            self.refresh_transposes()
         self.mark_shadow_current()
 
     def mark_shadow_current(self) -> None:

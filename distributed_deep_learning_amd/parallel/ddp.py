@@ -65,6 +65,9 @@ class DistributedDataParallel(tnn.Module):
         if self.dist:
             for p, s in zip(arena.params, arena.segments):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(s.bucket)))
+            # kernels that accumulate straight into the arena gradient report readiness through the arena
+            seg_bucket = [s.bucket for s in arena.segments]
+            arena.on_grad_ready = lambda seg: self._param_ready(seg_bucket[seg])
 
     # ------------------------------------------------------------------ setup
     def sync_parameters(self) -> None:
@@ -90,12 +93,15 @@ class DistributedDataParallel(tnn.Module):
         self._armed = True
 
     # ------------------------------------------------------------------ hooks
+    def _param_ready(self, bucket: int) -> None:
+        if not (self._armed and self.require_sync):
+            return
+        self._pending[bucket] -= 1
+        self._drain()
+
     def _make_hook(self, bucket: int):
         def hook(_param):
-            if not (self._armed and self.require_sync):
-                return
-            self._pending[bucket] -= 1
-            self._drain()
+            self._param_ready(bucket)
         return hook
 
     def _drain(self) -> None:

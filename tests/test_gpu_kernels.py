@@ -103,7 +103,10 @@ def test_bn_train_fwd_bwd(shape, relu, res):
 
     slab = K.bn_stats(x)
     vec = K.bn_finalize(slab, N * H * W, gamma, beta, rm, rv, mom, eps)
-    y = K.bn_apply(x, vec[2], vec[3], residual=r, relu=relu)
+    y, mask = K.bn_apply(x, vec[2], vec[3], residual=r, relu=relu, want_mask=True)
+    if relu:
+        bits = ((mask.long().unsqueeze(-1) >> torch.arange(8, device=mask.device)) & 1).reshape(N, H, W, C).permute(0, 3, 1, 2)
+        assert torch.equal(bits.bool(), y.float() > 0), "ReLU bit mask mismatch"
 
     xf = x.float().requires_grad_(True)
     rf = r.float().requires_grad_(True) if res else None
@@ -120,7 +123,7 @@ def test_bn_train_fwd_bwd(shape, relu, res):
 
     dy = _rand_act(shape, 14)
     # use the kernel's own y for the ReLU mask so rounding at 0 cannot flip elements between impls
-    dx, dres, dgamma, dbeta = K.bn_backward(dy, y, x, gamma, vec[0], vec[1], relu=relu, want_dres=res)
+    dx, dres, dgamma, dbeta = K.bn_backward(dy, mask, x, gamma, vec[0], vec[1], relu=relu, want_dres=res)
     mask = (y.float() > 0).float() if relu else torch.ones_like(y, dtype=torch.float32)
     # reference backward with the same mask: d(pre-relu) = dy * mask
     pre = F.batch_norm(xf, None, None, gp, bp, True, mom, eps)

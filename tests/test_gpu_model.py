@@ -1,0 +1,176 @@
+"""GPU integration: fused units vs stock torch layers, fused optimizer vs its CPU path, end-to-end training."""
+import copy
+
+import pytest
+import torch
+import torch.nn as tnn
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def test_kernel_library_is_loaded_in_tree():
+    from distributed_deep_learning_amd.ops import _lib
+    _lib.require()
+    maps = open("/proc/self/maps").read()
+    assert "libddl_hip.so" in maps, "the HIP kernel library must be the code that runs on the GPU box"
+
+
+def _ref_bottleneck(block, x):
+    """fp32 reference of a Bottleneck using stock torch ops on the same (master) weights."""
+    def cbr(conv, bn, inp, relu=True, res=None):
+        y = TF.conv2d(inp, conv.weight.float(), None, conv.stride, conv.padding)
+        y = TF.batch_norm(y, None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+        if res is not None:
+            y = y + res
+        return TF.relu(y) if relu else y
+    idt = x
+    o = cbr(block.conv1, block.bn1, x)
+    o = cbr(block.conv2, block.bn2, o)
+    if block.downsample is not None:
+        idt = cbr(block.downsample[0], block.downsample[1], x, relu=False)
+    return cbr(block.conv3, block.bn3, o, res=idt)
+
+
+@pytest.mark.parametrize("stride,inp,planes", [(1, 256, 64), (2, 256, 128)])
+def test_bottleneck_matches_fp32_reference(stride, inp, planes):
+    from distributed_deep_learning_amd.models.resnet import Bottleneck, _conv1x1
+    from distributed_deep_learning_amd import nn as dnn
+    torch.manual_seed(0)
+    down = None
+    if stride != 1 or inp != planes * 4:
+        down = tnn.Sequential(_conv1x1(inp, planes * 4, stride), dnn.BatchNorm2d(planes * 4))
+    blk = Bottleneck(inp, planes, stride, down).to(_dev())
+    for m in blk.modules():
+        if isinstance(m, tnn.BatchNorm2d):
+            tnn.init.uniform_(m.weight, 0.5, 1.5)
+            tnn.init.normal_(m.bias, 0, 0.1)
+    ref = copy.deepcopy(blk)
+    x = torch.randn(8, inp, 14, 14, device=_dev())
+    xb = x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    xr = xb.detach().float().requires_grad_(True)
+    y = blk(xb)
+    yr = _ref_bottleneck(ref, xr)
+    assert (y.float() - yr).abs().max() < 0.15 and (y.float() - yr).abs().mean() < 0.01
+    g = torch.randn_like(yr)
+    y.backward(g.to(torch.bfloat16))
+    yr.backward(g)
+    rel = lambda a, b: ((a.float() - b).norm() / (b.norm() + 1e-12)).item()  # noqa: E731
+    assert rel(xb.grad, xr.grad) < 0.05
+    for (n, p), (_, q) in zip(blk.named_parameters(), ref.named_parameters()):
+        assert rel(p.grad, q.grad) < 0.06, (n, rel(p.grad, q.grad))
+    # running statistics follow PyTorch semantics
+    assert torch.allclose(blk.bn1.running_var, 0.9 + 0.1 * TF.conv2d(xr, ref.conv1.weight.float()).var((0, 2, 3)), rtol=2e-2, atol=1e-3)
+    sd = blk.state_dict()
+    assert int(sd["bn1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("kind", ["sgd", "lars", "adam"])
+def test_fused_optimizer_kernel_matches_cpu_path(kind):
+    from distributed_deep_learning_amd.optim import LARS, FusedAdam, FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+
+    def make(device):
+        torch.manual_seed(0)
+        m = tnn.Sequential(tnn.Conv2d(8, 16, 3), tnn.BatchNorm2d(16), tnn.Flatten(), tnn.Linear(16 * 36, 10)).to(device)
+        a = ParamArena(m.named_parameters())
+        if kind == "sgd":
+            o = FusedSGD(a, lr=0.1, momentum=0.9, weight_decay=1e-2, nesterov=True)
+        elif kind == "lars":
+            o = LARS(a, lr=0.5, momentum=0.9, weight_decay=1e-3, eta=0.01)
+        else:
+            o = FusedAdam(a, lr=1e-2, weight_decay=1e-3)
+        return m, a, o
+
+    mc, ac, oc = make(torch.device("cpu"))
+    mg, ag, og = make(_dev())
+    g = torch.Generator().manual_seed(1)
+    for _ in range(4):
+        grad = torch.randn(ac.total, generator=g)
+        # only real elements carry gradient (padding stays zero, as after a real backward)
+        maskv = torch.zeros(ac.total)
+        for s in ac.segments:
+            maskv[s.offset:s.offset + s.numel] = 1
+        grad *= maskv
+        ac.grad.copy_(grad)
+        ag.grad.copy_(grad.to(_dev()))
+        oc.step()
+        og.step()
+    assert torch.allclose(ag.master.cpu(), ac.master, rtol=2e-5, atol=2e-6)
+    assert float(ag.grad.abs().sum()) == 0.0                                  # fused zero-grad
+    assert torch.equal(ag.shadow.float().cpu(), ag.master.to(torch.bfloat16).float().cpu())   # bf16 shadow rewritten
+    conv = ag.params[0]
+    assert torch.equal(conv._ddl_shadow_t.permute(3, 0, 1, 2).float(), conv.detach().to(torch.bfloat16).float())
+
+
+def test_resnet18_cifar_loss_decreases_and_matches_eval():
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+    torch.manual_seed(0)
+    model = models.resnet18_cifar().to(_dev())
+    arena = ParamArena(model.named_parameters())
+    opt = FusedSGD(arena, lr=0.05, momentum=0.9)
+    crit = SoftmaxCrossEntropyLoss()
+    x = torch.randn(64, 3, 32, 32, device=_dev())
+    y = torch.randint(0, 10, (64,), device=_dev())
+    losses = []
+    for _ in range(50):
+        loss = crit(model(x), y)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert losses[-1] < 0.5 * losses[0], losses[::10]
+    model.eval()
+    with torch.no_grad():
+        out = model(x)
+    assert out.shape == (64, 10) and torch.isfinite(out.float()).all()
+    arena.check_layout()
+
+
+def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
+    """RCCL communicator init + in-place collectives on arena buckets with world_size = 1 (identity)."""
+    import os
+    import torch.distributed as td
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
+    try:
+        t = torch.arange(8, dtype=torch.float32, device=_dev())
+        td.all_reduce(t)
+        assert torch.equal(t.cpu(), torch.arange(8, dtype=torch.float32))
+        torch.manual_seed(0)
+        model = models.resnet18_cifar().to(_dev())
+        ddp = DistributedDataParallel(model, bucket_mb=8)
+        assert not ddp.dist                      # world 1: reducer is a pass-through
+        opt = FusedSGD(ddp.arena, lr=0.05, momentum=0.9)
+        crit = SoftmaxCrossEntropyLoss()
+        x = torch.randn(32, 3, 32, 32, device=_dev())
+        y = torch.randint(0, 10, (32,), device=_dev())
+        l0 = None
+        for _ in range(5):
+            loss = crit(ddp(x), y)
+            loss.backward()
+            ddp.step(opt)
+            l0 = l0 or float(loss.detach())
+        assert float(loss.detach()) < l0
+    finally:
+        td.destroy_process_group()
+
+
+def test_trainer_gpu_cnn_reference_workload():
+    """The reference's CNN workload (DenseNet variant, 64x64 crops, one-hot targets) end to end on the GPU."""
+    from distributed_deep_learning_amd.config import Config
+    from distributed_deep_learning_amd.trainer import Trainer
+    lines = []
+    cfg = Config(model="cnn", device="gpu", epochs=2, batch=32, samples=512, lr=0.01)
+    hist = Trainer(cfg, printer=lines.append).setup().fit()
+    assert len(lines) == 7 and hist[1]["train_loss"] < hist[0]["train_loss"] * 1.05
