@@ -14,6 +14,7 @@
 // while the atomic traffic stays a small multiple of the weight size.
 #include "common.h"
 #include "host_util.h"
+#include <stdlib.h>
 
 struct WgradParams {
   const bf16_t* dy;   // [M][K]
@@ -52,12 +53,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wk = wid & 1, wn = wid >> 1;
 
-  // block -> (k tile, n tile, r, split); splits fastest so one tile's atomics come from neighbouring blocks
-  unsigned b = blockIdx.x;
-  const int split = b % p.splits; b /= p.splits;
+  // block -> (split, r, k tile, n tile), tiles fastest after the XCD remap: the tiles of one M-slice run
+  // together on one XCD, so the dy / x rows they all stream are fetched from HBM once and re-read from that L2.
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = b % p.tiles_n; b /= p.tiles_n;
   const int tk = b % p.tiles_k; b /= p.tiles_k;
-  const int r = (int)b;
+  const int r = b % p.R; b /= p.R;
+  const int split = (int)b;
   const int k0 = tk * TK, nn0 = tn * TN;
 
   const int m_begin = split * p.m_per_split;
@@ -175,22 +177,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: D[row = k channel][col = (s,c)] -> atomic accumulate ----
+  // ---- epilogue: D[row = k channel][col = (s,c)] -> fp32 tile in LDS -> row-contiguous float atomics ----
+  // (each wave-instruction adds 256 contiguous bytes of one dw row: the shape the memory-side atomic units like)
   if (nsteps > 0) {
+    float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TN] fp32, reuses the staging buffers
 #pragma unroll
-    for (int i = 0; i < FK; ++i) {
+    for (int i = 0; i < FK; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int col = nn0 + wn * WN + j * 16 + (lane & 15);
+        const int col = wn * WN + j * 16 + (lane & 15);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int k = k0 + wk * WK + i * 16 + (lane >> 4) * 4 + e;
-          if (k < p.K && col < p.SC) {
-            float* dst = p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)col;
-            atomicAdd(dst, acc[i][j][e]);
-          }
+          const int row = wk * WK + i * 16 + (lane >> 4) * 4 + e;
+          Ts[row * TN + col] = acc[i][j][e];
         }
       }
+    __syncthreads();
+    constexpr int LPR = TN / 64;                                // 64-lane pieces per row
+    for (int it = wid; it < TK * LPR; it += 4) {
+      const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
+      const int k = k0 + row, cn = nn0 + col;
+      if (k < p.K && cn < p.SC)
+        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TN + col]);
     }
   }
 }
@@ -200,8 +208,14 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   p.tiles_k = (p.K + TK - 1) / TK;
   p.tiles_n = (p.SC + TN - 1) / TN;
   const long long tiles = (long long)p.tiles_k * p.tiles_n * p.R;
-  // Aim for ~1024 blocks; never make a split shorter than 256 pixels (4 K-steps).
-  long long splits = (1024 + tiles - 1) / tiles;
+  // One full round of resident blocks (2 per CU x 256 CUs), never more: a grid of 1.1 rounds runs as long as 2,
+  // and every extra split adds a tile of fp32 atomic traffic (~1.3 TB/s chip-wide).  Splits are never shorter
+  // than 256 pixels (4 K-steps).
+  const int smem = 2 * 64 * (TK + TN) * 2;
+  static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  const int per_cu = (160 * 1024) / smem < 4 ? (160 * 1024) / smem : 4;      // LDS- and register-limited residency
+  const long long capacity = cap_env > 0 ? cap_env : 256 * per_cu;
+  long long splits = capacity / tiles;
   const long long max_splits = (p.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -210,7 +224,6 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   splits = (p.M + mps - 1) / mps;
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
-  const int smem = 2 * 64 * (TK + TN) * 2;
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<TK, TN>), smem);
   if (rc != 0) return rc;
