@@ -223,14 +223,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict__ slab, int nslots, int C, float count,
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, float* __restrict__ coefA,
+                                       float* __restrict__ dbeta, int accumulate, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC) {
   float sg, sgx;
   slab_fold(slab, nslots, C, sg, sgx);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || c >= C) return;
-  dgamma[c] = sgx;
-  dbeta[c] = sg;
+  if (accumulate) { dgamma[c] += sgx; dbeta[c] += sg; }      // straight into the arena gradient
+  else            { dgamma[c] = sgx;  dbeta[c] = sg; }
   const float g = gamma ? gamma[c] : 1.f;
   const float sc = g * invstd[c];
   const float mg = sg / count, mgx = sgx / count;
@@ -314,7 +314,7 @@ extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask,
 // Full backward.  slab must be ZERO on entry (it is left zero again).  mask: the [M][C/8] ReLU bit mask written by ddl_bn_apply (required when relu).  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
 extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, const float* gamma, const float* mean,
                                const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
-                               float* coef, int M, int C, int relu, void* stream) {
+                               float* coef, int M, int C, int relu, int accumulate, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
   const RowMap rm = make_rowmap(M, C);
@@ -325,7 +325,7 @@ extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, 
   else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
   float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
-                     mean, invstd, dgamma, dbeta, cA, cB, cC);
+                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
   bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
   if (relu) {
     if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);

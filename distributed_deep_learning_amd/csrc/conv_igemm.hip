@@ -25,6 +25,7 @@ struct ConvParams {
   const bf16_t* wmat;
   bf16_t* out;
   const float* bias;   // optional [OC]
+  const bf16_t* addend; // optional, same shape as out: out = conv + addend (gradient accumulation fused in dgrad)
   float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
   int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;
   int M, Kred;
@@ -236,7 +237,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int ow = rem - oh * p.OW;
         opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
       }
-      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = v;
+      u32x4 vo = v;
+      if (p.addend != nullptr) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + opix * (size_t)p.OC + (size_t)ncol);
+        float f[8], a[8];
+        unpack8(v, f);
+        unpack8(av, a);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] += a[q];
+        vo = pack8(f);
+      }
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
       if (p.stats != nullptr) {
         float f[8];
         unpack8(v, f);
@@ -292,7 +303,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
 }
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
-                              int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              const void* addend, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
@@ -300,6 +311,8 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   if (M >= (1ll << 31) || (long long)N * IH * IW >= (1ll << 31)) return -3;
   ConvParams p;
   p.in = (const bf16_t*)in; p.wmat = (const bf16_t*)wmat; p.out = (bf16_t*)out; p.bias = bias; p.stats = stats;
+  p.addend = (const bf16_t*)addend;
+  if (addend != nullptr && stats != nullptr) return -5;      // statistics are taken before the addend
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;
@@ -318,6 +331,7 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
       const int r0 = (ph + pad) % stride, s0 = (pw + pad) % stride;
       if (r0 >= R || s0 >= S || ph >= OH || pw >= OW) { any_empty = true; break; }
     }
+  if (any_empty && addend != nullptr) return -4;             // the zero-filled pixels would miss the addend
   if (any_empty) {   // classes without a contributing tap (e.g. 1x1 stride-2) are plain zeros
     hipError_t e = hipMemsetAsync(out, 0, sizeof(bf16_t) * (size_t)M * (size_t)OC, st);
     if (e != hipSuccess) return (int)e;

@@ -15,7 +15,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
-from ..nn.modules import conv_bn_act, to_device_input
+from ..nn.modules import conv_bn_act, residual_block, to_device_input
 
 
 def _conv3x3(cin, cout, stride=1):
@@ -38,11 +38,8 @@ class BasicBlock(tnn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x
-        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        if self.downsample is not None:
-            identity = conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        return conv_bn_act(self.conv2, self.bn2, out, relu=True, residual=identity)
+        ds = (self.downsample[0], self.downsample[1]) if self.downsample is not None else None
+        return residual_block([(self.conv1, self.bn1), (self.conv2, self.bn2)], ds, x)
 
 
 class Bottleneck(tnn.Module):
@@ -59,12 +56,8 @@ class Bottleneck(tnn.Module):
         self.downsample = downsample
 
     def forward(self, x):
-        identity = x
-        out = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        out = conv_bn_act(self.conv2, self.bn2, out, relu=True)
-        if self.downsample is not None:
-            identity = conv_bn_act(self.downsample[0], self.downsample[1], x, relu=False)
-        return conv_bn_act(self.conv3, self.bn3, out, relu=True, residual=identity)
+        ds = (self.downsample[0], self.downsample[1]) if self.downsample is not None else None
+        return residual_block([(self.conv1, self.bn1), (self.conv2, self.bn2), (self.conv3, self.bn3)], ds, x)
 
 
 class ResNet(tnn.Module):

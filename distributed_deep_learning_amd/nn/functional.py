@@ -35,6 +35,27 @@ def _wgrad(weight, dy, x, R, S, stride, pad, cin_real):
     return dw
 
 
+def _bn_grad_out(gamma, beta):
+    """(dgamma, dbeta) arena views to accumulate into, or None when the parameters are not arena-backed."""
+    arena = getattr(gamma, "_ddl_arena", None)
+    if (arena is not None and getattr(beta, "_ddl_arena", None) is arena and arena.grad_is_arena_view(gamma)
+            and arena.grad_is_arena_view(beta)):
+        return arena, (gamma.grad, beta.grad)
+    return None, None
+
+
+def _bn_bwd(dout, mask, x_bn, gamma_p, beta_p, gamma, mean, invstd, relu, want_dres, slab):
+    """BN(+ReLU) backward; parameter gradients go straight into the arena when possible (then returned as None)."""
+    arena, gout = _bn_grad_out(gamma_p, beta_p)
+    dx, dres, dgamma, dbeta = K.bn_backward(dout, mask, x_bn, gamma, mean, invstd, relu=relu, want_dres=want_dres,
+                                            slab=slab, grad_out=gout)
+    if arena is not None:
+        arena.notify_grad_ready(gamma_p)
+        arena.notify_grad_ready(beta_p)
+        dgamma = dbeta = None
+    return dx, dres, dgamma, dbeta
+
+
 class ConvBNAct(torch.autograd.Function):
     """y = act(BN_train(conv(x, w)) [+ residual]) with BN statistics fused into the conv epilogue."""
 
@@ -50,6 +71,7 @@ class ConvBNAct(torch.autograd.Function):
         ctx.save_for_backward(x, y_conv, mask, vec, gamma, w_crsk)
         ctx.geom = (stride, pad, relu, residual is not None, w_krsc.shape[1], w_krsc.shape[2], cin_real)
         ctx.weight = weight
+        ctx.bn_params = (gamma, beta)
         ctx.slab = slabs[1] if slabs else None
         return out
 
@@ -58,13 +80,103 @@ class ConvBNAct(torch.autograd.Function):
         x, y_conv, mask, vec, gamma, w_crsk = ctx.saved_tensors
         stride, pad, relu, has_res, R, S, cin_real = ctx.geom
         dout = K.nhwc(_bf16(dout))
-        dconv, dres, dgamma, dbeta = K.bn_backward(dout, mask, y_conv, gamma, vec[0], vec[1], relu=relu,
-                                                   want_dres=has_res, slab=ctx.slab)
+        dconv, dres, dgamma, dbeta = _bn_bwd(dout, mask, y_conv, ctx.bn_params[0], ctx.bn_params[1], gamma, vec[0],
+                                             vec[1], relu, has_res, ctx.slab)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dconv, w_crsk, tuple(x.shape[2:]), stride, pad)
         dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
         return (dx, dw, dgamma, dbeta, dres) + (None,) * 11
+
+
+class ResidualBlock(torch.autograd.Function):
+    """A whole residual block (ResNet BasicBlock / Bottleneck) as ONE autograd node.
+
+    ``units`` = main-path (conv, bn) pairs, every one followed by ReLU; the last one adds the shortcut before its
+    ReLU.  ``ds`` = optional (conv, bn) projection shortcut.  Owning the block's backward lets the gradient of the
+    block input be accumulated inside the first conv's dgrad epilogue (``addend``) instead of a separate add
+    kernel, keeps every filter / BN gradient flowing straight into the arena, and replaces ~4 autograd nodes and
+    their Python dispatch by one.  Parameters are passed as inputs (so non-arena setups still get gradients back).
+    """
+
+    @staticmethod
+    def forward(ctx, x, units, ds, *params):
+        x = K.nhwc(_bf16(x))
+        saved, metas = [], []
+
+        def run(conv, bn, inp, relu, residual):
+            krsc, crsk = conv.packed()
+            slabs = bn.slabs(inp.device)
+            bn._count_batch()
+            y_conv, stats = K.conv2d_fwd(inp, krsc, conv.stride[0], conv.padding[0], want_stats=True, slab=slabs[0])
+            n, _, p_, q_ = y_conv.shape
+            vec = K.bn_finalize(stats, n * p_ * q_, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                bn._momentum(), bn.eps)
+            out, mask = K.bn_apply(y_conv, vec[2], vec[3], residual=residual, relu=relu, want_mask=True)
+            saved.extend([inp, y_conv, mask, vec, crsk])
+            metas.append((conv, bn, relu, residual is not None, slabs[1]))
+            return out
+
+        identity = x
+        if ds is not None:
+            identity = run(ds[0], ds[1], x, False, None)
+        h = x
+        for i, (conv, bn) in enumerate(units):
+            last = i == len(units) - 1
+            h = run(conv, bn, h, True, identity if last else None)
+        ctx.save_for_backward(*saved)
+        ctx.metas = metas
+        ctx.has_ds = ds is not None
+        ctx.nparams = len(params)
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        metas = ctx.metas
+        grads = {}
+
+        def back(idx, dy, need_dx, addend=None):
+            inp, y_conv, mask, vec, crsk = saved[5 * idx:5 * idx + 5]
+            conv, bn, relu, has_res, slab = metas[idx]
+            dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, vec[0], vec[1],
+                                                 relu, has_res, slab)
+            dx = None
+            if need_dx:
+                dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend)
+            R, S = conv.kernel_size
+            dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
+            grads[idx] = (dw, dgamma, dbeta)
+            return dx, dres
+
+        dout = K.nhwc(_bf16(dout))
+        first_main = 1 if ctx.has_ds else 0
+        n_units = len(metas)
+        need_x = ctx.needs_input_grad[0]
+        d = dout
+        dres = None
+        for idx in range(n_units - 1, first_main, -1):          # main path, last unit first
+            d, r = back(idx, d, True)
+            if r is not None:
+                dres = r
+        if n_units - 1 == first_main:                            # single main unit (not used by ResNet)
+            pass
+        # first main unit: its dgrad epilogue also adds the shortcut's gradient
+        if ctx.has_ds:
+            dshort, _ = back(0, dres, need_x)                    # projection shortcut: gradient w.r.t. the block input
+        else:
+            dshort = dres
+        if n_units - 1 > first_main:
+            dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None)
+        else:                                                    # degenerate: the only main unit carries the residual
+            dx, r = back(first_main, d, need_x)
+            if need_x and r is not None:
+                dx = K.add(dx, r if not ctx.has_ds else dshort)
+        out = []
+        for idx in range(n_units):
+            out.extend(grads[idx])
+        # parameter order given to apply(): ds first (if any), then the main units — same as metas
+        return (dx, None, None, *out)
 
 
 class ConvBiasAct(torch.autograd.Function):
@@ -103,6 +215,7 @@ class BNAct(torch.autograd.Function):
         N, _, H, W = x.shape
         slab = K.bn_stats(x, slab=slabs[0] if slabs else None)
         ctx.slab = slabs[1] if slabs else None
+        ctx.bn_params = (gamma, beta)
         vec = K.bn_finalize(slab, N * H * W, gamma, beta, running_mean, running_var, momentum, eps)
         res = K.nhwc(_bf16(residual)) if residual is not None else None
         out, mask = K.bn_apply(x, vec[2], vec[3], residual=res, relu=relu, want_mask=True)
@@ -115,8 +228,8 @@ class BNAct(torch.autograd.Function):
         x, mask, vec, gamma = ctx.saved_tensors
         relu, has_res = ctx.flags
         dout = K.nhwc(_bf16(dout))
-        dx, dres, dgamma, dbeta = K.bn_backward(dout, mask, x, gamma, vec[0], vec[1], relu=relu, want_dres=has_res,
-                                                slab=ctx.slab)
+        dx, dres, dgamma, dbeta = _bn_bwd(dout, mask, x, ctx.bn_params[0], ctx.bn_params[1], gamma, vec[0], vec[1],
+                                          relu, has_res, ctx.slab)
         return (dx, dgamma, dbeta, dres) + (None,) * 6
 
 

@@ -187,6 +187,25 @@ def conv_bn_act(conv: Conv2d, bn: BatchNorm2d, x, relu: bool = True, residual=No
     return bn(conv(x), residual=residual, relu=relu)
 
 
+def residual_block(units, ds, x):
+    """Run a residual block — ``units``: main-path (conv, bn) pairs, ``ds``: optional projection (conv, bn) — as one
+    fused autograd node on the GPU (see :class:`functional.ResidualBlock`); layer-by-layer elsewhere."""
+    mods = ([ds] if ds is not None else []) + list(units)
+    fused = (x.is_cuda and torch.is_grad_enabled() and len(units) >= 2 and x.shape[1] % 8 == 0
+             and all(c.bias is None and c._native_ok() and c.in_channels % 8 == 0 and b.training
+                     and b.track_running_stats and b.affine for c, b in mods))
+    if fused:
+        params = []
+        for c, b in mods:
+            params += [c.weight, b.weight, b.bias]
+        return F.ResidualBlock.apply(x, tuple(units), ds, *params)
+    identity = x if ds is None else conv_bn_act(ds[0], ds[1], x, relu=False)
+    h = x
+    for i, (c, b) in enumerate(units):
+        h = conv_bn_act(c, b, h, relu=True, residual=identity if i == len(units) - 1 else None)
+    return h
+
+
 class ReLU(tnn.Module):
     def __init__(self, inplace: bool = False):
         super().__init__()

@@ -79,13 +79,14 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
         raise TypeError("conv2d_fwd: bias must be fp32 [K]")
-    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), N, P, Q, H, W, Cc, K, R, S,
+    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, N, P, Q, H, W, Cc, K, R, S,
                              stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
     return y, stats
 
 
-def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0):
-    """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC)."""
+def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None):
+    """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC).
+    ``addend`` (bf16, shape of dx) is added in the epilogue: gradient accumulation of a second path for free."""
     lib = _lib.require()
     _chk_act(dy, "conv2d_dgrad")
     dy = nhwc(dy)
@@ -97,8 +98,15 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0):
     if conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
         raise ValueError("conv2d_dgrad: geometry mismatch")
     dx = torch.empty((N, Cc, H, W), dtype=BF16, device=dy.device, memory_format=CL)
-    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, N, H, W, P, Q, K, Cc, R, S, stride, pad,
-                             0, stream_ptr()), "conv2d_dgrad")
+    if addend is not None:
+        _chk_act(addend, "conv2d_dgrad(addend)")
+        addend = nhwc(addend)
+        if addend.shape != dx.shape:
+            raise ValueError("conv2d_dgrad: addend shape mismatch")
+        if stride > 1 and (R < stride or S < stride):
+            raise ValueError("conv2d_dgrad: addend not supported when stride exceeds the filter size")
+    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, ptr(addend), N, H, W, P, Q, K, Cc, R, S,
+                             stride, pad, 0, stream_ptr()), "conv2d_dgrad")
     return dx
 
 
@@ -168,7 +176,7 @@ def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False):
     return (y, mask) if want_mask else y
 
 
-def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, slab=None):
+def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, slab=None, grad_out=None):
     """Returns ``(dx, dres or None, dgamma, dbeta)``; ``mask`` is the bit mask from :func:`bn_apply` (``relu`` only)."""
     lib = _lib.require()
     _chk_act(dy, "bn_backward")
@@ -178,13 +186,20 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
         raise ValueError("bn_backward: relu=True needs the uint8 [N*H*W, C/8] mask from bn_apply(want_mask=True)")
     dx = torch.empty_like(x, memory_format=CL)
     dres = torch.empty_like(x, memory_format=CL) if want_dres else None
-    dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+    if grad_out is not None:       # (dgamma, dbeta) fp32 [C] tensors to ACCUMULATE into (arena gradient views)
+        dg, db = grad_out
+        if not (dg.is_contiguous() and db.is_contiguous() and dg.numel() == Cc and db.numel() == Cc
+                and dg.dtype == torch.float32 and db.dtype == torch.float32):
+            raise ValueError("bn_backward: grad_out must be two contiguous fp32 [C] tensors")
+        dgb = (dg, db)
+    else:
+        dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     if slab is None:
         slab = new_slab(Cc, x.device)
     coef = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
     check(lib.ddl_bn_backward(ptr(dy), ptr(mask) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
-                              stream_ptr()), "bn_backward")
+                              int(grad_out is not None), stream_ptr()), "bn_backward")
     return dx, dres, dgb[0], dgb[1]
 
 
