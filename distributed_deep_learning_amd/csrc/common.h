@@ -27,8 +27,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+
+// Two floats -> packed bf16 pair with ONE v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN preserved).
 __device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
-  return (unsigned int)f32_to_bf16(lo) | ((unsigned int)f32_to_bf16(hi) << 16);
+  const f32x2_t v = {lo, hi};
+  const bf16x2_t b = __builtin_convertvector(v, bf16x2_t);
+  return __builtin_bit_cast(unsigned int, b);
 }
 
 __device__ __forceinline__ void unpack8(const u32x4& v, float* f) {

@@ -19,23 +19,9 @@
 // fuse bias+ReLU and the per-channel sum / sum-of-squares partials that BatchNorm needs (no extra read pass).
 #include "common.h"
 #include "host_util.h"
+#include "conv_params.h"
+#include <stdlib.h>
 
-struct ConvParams {
-  const bf16_t* in;
-  const bf16_t* wmat;
-  bf16_t* out;
-  const float* bias;   // optional [OC]
-  const bf16_t* addend; // optional, same shape as out: out = conv + addend (gradient accumulation fused in dgrad)
-  float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
-  int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;
-  int M, Kred;
-  int tiles_m, tiles_n;
-  int relu;
-  // row grid -> output pixel: (oh*o_step + o_ph, ow*o_step + o_pw) inside a [N][FOH][FOW] tensor
-  int o_step, o_ph, o_pw, FOH, FOW;
-  // tap subset: r = r0 + tr*t_step (tr < nR), s = s0 + ts*t_step (ts < nS); Kred = nR*nS*IC; KredFull = R*S*IC
-  int r0, s0, t_step, nR, nS, KredFull;
-};
 
 template <int BM, int BN, int MODE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
@@ -293,8 +279,13 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 
 template <int MODE>
 static int launch_any(ConvParams& p, hipStream_t st) {
+  // default: the 3-stage LDS-DMA ring kernel (conv_ring.hip); DDL_CONV_RING=0 selects the register-staged kernel
+  static const int use_ring = [] { const char* e = getenv("DDL_CONV_RING"); return e ? atoi(e) : 1; }();
+  p.mode_hint = MODE;
+  if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
   p.tiles_m = (p.M + 127) / 128;
-  if (p.OC <= 64) {
+  static const int force64 = [] { const char* e = getenv("DDL_CONV_BN64"); return e ? atoi(e) : 0; }();
+  if (p.OC <= 64 || force64) {
     p.tiles_n = (p.OC + 63) / 64;
     return launch_conv<128, 64, MODE>(p, st);
   }
@@ -316,6 +307,8 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;
+  p.in_bytes = 2ull * (unsigned long long)N * IH * IW * IC;
+  p.w_bytes = 2ull * (unsigned long long)OC * p.KredFull;
   p.FOH = OH; p.FOW = OW;
   hipStream_t st = (hipStream_t)stream;
   if (mode == 0 || stride == 1) {

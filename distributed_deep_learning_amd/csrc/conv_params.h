@@ -1,0 +1,27 @@
+// Parameter block shared by the implicit-GEMM convolution kernels (conv_igemm.hip, conv_ring.hip).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+  const bf16_t* in;
+  const bf16_t* wmat;
+  bf16_t* out;
+  const float* bias;   // optional [OC]
+  const bf16_t* addend; // optional, same shape as out: out = conv + addend (gradient accumulation fused in dgrad)
+  float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
+  int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;
+  int M, Kred;
+  int tiles_m, tiles_n;
+  int relu;
+  // row grid -> output pixel: (oh*o_step + o_ph, ow*o_step + o_pw) inside a [N][FOH][FOW] tensor
+  int o_step, o_ph, o_pw, FOH, FOW;
+  // tap subset: r = r0 + tr*t_step (tr < nR), s = s0 + ts*t_step (ts < nS); Kred = nR*nS*IC; KredFull = R*S*IC
+  int r0, s0, t_step, nR, nS, KredFull;
+  unsigned long long in_bytes, w_bytes;
+  FastDiv div_ohw, div_ow;
+  int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
+};
+
+// conv_ring.hip
+bool ddl_conv_ring_supported(const ConvParams& p);
+int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream);

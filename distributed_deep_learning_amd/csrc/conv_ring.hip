@@ -1,0 +1,312 @@
+// Implicit-GEMM convolution, LDS-DMA ring version (gfx950): forward and data-gradient.
+//
+// Same math, operand roles, LDS swizzle and epilogue as conv_igemm.hip; what changes is the staging pipeline.
+// The register-staged kernel keeps ONE K-step of loads in flight and pays a full memory round trip per 64-deep
+// K-step — fatal for the short reductions of ResNet's 1x1 convs (4..32 K-steps).  Here:
+//
+//   * tile 256 pixels x BN channels x 64, 512 threads = 8 waves (4 x 2), one block per CU;
+//   * both operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, no
+//     VGPRs), into a 3-stage ring, so TWO K-steps of loads are always in flight behind the one being multiplied;
+//   * zero fill (conv padding, M / N / K tails) costs nothing: lanes that must read zero use an out-of-range
+//     buffer offset, for which the LDS-DMA writes zeros (probe: bench/probes/lds_dma_oob.hip);
+//   * the XOR swizzle that keeps ds_read_b128 conflict-free is applied on the per-lane SOURCE address (the LDS
+//     destination of an LDS-DMA is lane-linear) and on the fragment read;
+//   * one raw s_barrier per K-step with a COUNTED s_waitcnt vmcnt(6) (= the next stage's six loads stay in
+//     flight across the barrier); the loads are issued from inline asm so hipcc neither counts nor drains them.
+#include "common.h"
+#include "host_util.h"
+#include "conv_params.h"
+
+namespace {
+
+constexpr int RBM = 256;      // pixels per tile
+constexpr int RBK = 64;       // reduction per stage
+constexpr int RNS = 3;        // ring stages
+
+// One LDS-DMA: 64 lanes x 16 bytes -> 1 KiB at `lds_byte` (wave-uniform), each lane from rsrc + voff (bytes).
+__device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+}
+
+// EPI bits: 1 = bias / ReLU epilogue, 2 = BN partial sums, 4 = addend (compile-time, so unused paths cost nothing)
+template <int BN, int MODE, int EPI>
+__global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
+  constexpr int XBYTES = RBM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
+  constexpr int WJ = BN / 64;               // W LDS-DMA instructions per thread per stage (X: 4)
+  constexpr int WM = 64, WN = BN / 2;       // per-wave sub-tile: 64 pixels x WN channels
+  constexpr int TM = WM / 16, TN = WN / 16;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid & 3, wn = wid >> 2;
+
+  const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = lid / p.tiles_n, tile_n = lid - tile_m * p.tiles_n;
+  const int m0 = tile_m * RBM, n0 = tile_n * BN;
+
+  // buffer descriptors (wave-uniform: built from kernel arguments only)
+  const __amdgpu_buffer_rsrc_t xsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, (int)p.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.wmat, 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- staging geometry: wave w, instruction j writes LDS rows (j*8 + w)*8 .. +7, lane -> (row lane>>3, physical
+  //      chunk lane&7); the logical chunk is the same for every row of a thread.
+  const int lrow = lane >> 3;
+  const int lchunk = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);
+
+  int nb[4], bh[4], bw[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + (j * 8 + wid) * 8 + lrow;
+    if (m < p.M) {
+      const int n = (int)fastdiv((unsigned)m, p.div_ohw);
+      const int rem = m - n * (int)p.div_ohw.d;
+      const int oh = (int)fastdiv((unsigned)rem, p.div_ow);
+      const int ow = rem - oh * p.OW;
+      nb[j] = n * p.IH * p.IW;
+      if (MODE == 0) { bh[j] = oh * p.stride - p.pad; bw[j] = ow * p.stride - p.pad; }
+      else           { bh[j] = oh * p.o_step + p.o_ph + p.pad; bw[j] = ow * p.o_step + p.o_pw + p.pad; }
+    } else {
+      nb[j] = 0; bh[j] = -(1 << 28); bw[j] = -(1 << 28);
+    }
+  }
+  unsigned wrow_off[WJ];
+  bool wrow_ok[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const int n = n0 + (j * 8 + wid) * 8 + lrow;
+    wrow_ok[j] = n < p.OC;
+    wrow_off[j] = (unsigned)n * (unsigned)p.KredFull;
+  }
+  // reduction cursor of this thread's chunk: (tap row, tap col, channel) inside the tap subset
+  int kr, ks_, kc;
+  {
+    const int kk = lchunk * 8;
+    const int tap = kk / p.IC;
+    kc = kk - tap * p.IC;
+    kr = tap / p.nS;
+    ks_ = tap - kr * p.nS;
+  }
+
+  auto issue = [&](int stage) {
+    const int r = p.r0 + kr * p.t_step, sx = p.s0 + ks_ * p.t_step;
+    const bool kok = kr < p.nR;
+    char* const sbase = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int ih, iw; bool ok;
+      if (MODE == 0) {
+        ih = bh[j] + r; iw = bw[j] + sx;
+        ok = ((unsigned)ih < (unsigned)p.IH) && ((unsigned)iw < (unsigned)p.IW);
+      } else {
+        const int th = bh[j] - r, tw = bw[j] - sx;
+        if (p.stride == 1)      { ih = th; iw = tw; }
+        else if (p.stride == 2) { ih = th >> 1; iw = tw >> 1; }
+        else                    { ih = th / p.stride; iw = tw / p.stride; }
+        ok = (th >= 0) && (tw >= 0) && (ih < p.IH) && (iw < p.IW);
+      }
+      const unsigned off = ((unsigned)(nb[j] + ih * p.IW + iw) * (unsigned)p.IC + (unsigned)kc) * 2u;
+      lds_dma16(xsrc, sbase + (j * 8 + wid) * 1024, (ok && kok) ? off : OOB);
+    }
+    const unsigned woff = (unsigned)((r * p.S + sx) * p.IC + kc);
+#pragma unroll
+    for (int j = 0; j < WJ; ++j)
+      lds_dma16(wsrc, sbase + XBYTES + (j * 8 + wid) * 1024,
+                (wrow_ok[j] && kok) ? (wrow_off[j] + woff) * 2u : OOB);
+    // advance the cursor by one K-step
+    kc += RBK;
+    while (kc >= p.IC) {
+      kc -= p.IC;
+      if (++ks_ == p.nS) { ks_ = 0; ++kr; }
+    }
+  };
+
+  f32x4 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ksteps = (p.Kred + RBK - 1) / RBK;
+
+  issue(0);
+  if (ksteps > 1) issue(1);
+
+  int stage = 0;
+  for (int t = 0; t < ksteps; ++t) {
+    // tile t has landed once at most the NEXT tile's loads (4 + WJ per thread) are still outstanding
+    if (t + 1 < ksteps) {
+      if (WJ == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();           // everyone's part of tile t is in LDS; everyone is done with tile t-1
+    asm volatile("" ::: "memory");
+    if (t + 2 < ksteps) issue(stage == 0 ? 2 : stage - 1);      // refill the stage tile t-1 just vacated
+    const char* xb = smem + stage * STAGE;
+    const char* wb = xb + XBYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 a[TN], b[TM];
+      const int ch = ks * 4 + (lane >> 4);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int row = wn * WN + i * 16 + (lane & 15);
+        a[i] = *reinterpret_cast<const bf16x8*>(wb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        const int row = wm * WM + j * 16 + (lane & 15);
+        b[j] = *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    stage = (stage == RNS - 1) ? 0 : stage + 1;
+  }
+  __syncthreads();     // all fragment reads done (nothing is in flight any more): the ring becomes epilogue space
+
+  // ---- epilogue: acc -> (bias, relu) -> bf16 tile in LDS -> full-line global stores (+ addend, + BN partial sums) ----
+  constexpr int OPITCH = (BN + 8) * 2;
+  char* const Os = smem;
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    const int ch = wn * WN + i * 16 + (lane >> 4) * 4;
+    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((EPI & 1) && p.bias != nullptr) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bv[q] = (n0 + ch + q < p.OC) ? p.bias[n0 + ch + q] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+      const int px = wm * WM + j * 16 + (lane & 15);
+      float v[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q];
+      if (EPI & 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bv[q];
+        if (p.relu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
+        }
+      }
+      u32x2 pk;
+      pk[0] = pack_bf16x2(v[0], v[1]);
+      pk[1] = pack_bf16x2(v[2], v[3]);
+      *reinterpret_cast<u32x2*>(Os + px * OPITCH + ch * 2) = pk;
+    }
+  }
+  __syncthreads();
+
+  constexpr int CPR = BN / 8;       // 16-byte chunks per output row
+  constexpr int RPP = 512 / CPR;    // rows per pass
+  const int oc = tid % CPR, orow0 = tid / CPR;
+  const int ncol = n0 + oc * 8;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+#pragma unroll
+  for (int pass = 0; pass < RBM / RPP; ++pass) {
+    const int row = orow0 + pass * RPP;
+    const int m = m0 + row;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * OPITCH + oc * 16);
+    if (m < p.M && ncol < p.OC) {
+      size_t opix = (size_t)m;
+      if (MODE == 1 && p.o_step != 1) {
+        const int n = (int)fastdiv((unsigned)m, p.div_ohw);
+        const int rem = m - n * (int)p.div_ohw.d;
+        const int oh = (int)fastdiv((unsigned)rem, p.div_ow);
+        const int ow = rem - oh * p.OW;
+        opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
+      }
+      u32x4 vo = v;
+      if ((EPI & 4) && p.addend != nullptr) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + opix * (size_t)p.OC + (size_t)ncol);
+        float f[8], a[8];
+        unpack8(v, f);
+        unpack8(av, a);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] += a[q];
+        vo = pack8(f);
+      }
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
+      if (EPI & 2) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+      }
+    }
+  }
+  if (EPI & 2) {
+    constexpr int OS_BYTES = ((RBM * OPITCH + 15) / 16) * 16;
+    float* const red = reinterpret_cast<float*>(smem + OS_BYTES);   // [RPP][2][BN]
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
+      red[(orow0 * 2 + 1) * BN + oc * 8 + q] = s2[q];
+    }
+    __syncthreads();
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid - which * BN;
+      float s = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
+      if (n0 + col < p.OC)
+        atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
+    }
+  }
+}
+
+template <int BN, int MODE, int EPI>
+int launch_ring(ConvParams& p, hipStream_t stream) {
+  constexpr int smem = RNS * (RBM + BN) * 128;
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, MODE, EPI>), smem);
+  if (rc != 0) return rc;
+  p.tiles_m = (p.M + RBM - 1) / RBM;
+  p.tiles_n = (p.OC + BN - 1) / BN;
+  const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
+  hipLaunchKernelGGL((conv_ring_kernel<BN, MODE, EPI>), dim3(grid), dim3(512), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+template <int BN>
+int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
+  if (mode == 0) {
+    if (p.stats != nullptr) {
+      if (p.bias != nullptr || p.relu) return -6;               // statistics are taken of the raw conv output
+      return launch_ring<BN, 0, 2>(p, stream);
+    }
+    if (p.bias != nullptr || p.relu) return launch_ring<BN, 0, 1>(p, stream);
+    return launch_ring<BN, 0, 0>(p, stream);
+  }
+  if (p.addend != nullptr) return launch_ring<BN, 1, 4>(p, stream);
+  return launch_ring<BN, 1, 0>(p, stream);
+}
+
+}  // namespace
+
+// 32-bit byte offsets inside both operands, and room for the out-of-range sentinel above them.
+bool ddl_conv_ring_supported(const ConvParams& p) {
+  if (p.mode_hint == 1 && (p.bias != nullptr || p.relu || p.stats != nullptr)) return false;
+  if (p.mode_hint == 0 && p.addend != nullptr) return false;
+  if (p.stats != nullptr && (p.bias != nullptr || p.relu)) return false;
+  return p.in_bytes < 0xFFFF0000ull && p.w_bytes < 0xFFFF0000ull;
+}
+
+int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream) {
+  p.div_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
+  p.div_ow = make_fastdiv((unsigned)p.OW);
+  if (p.OC <= 64) return dispatch_ring<64>(p, mode, stream);
+  return dispatch_ring<128>(p, mode, stream);
+}
