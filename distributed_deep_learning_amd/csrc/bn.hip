@@ -141,7 +141,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   float sc[8], sh[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { sc[q] = scale[chunk * 8 + q]; sh[q] = shift[chunk * 8 + q]; }
-  for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+  // Rows are walked from the END of the tensor: the producer (conv epilogue / reduce pass) touched the tail last, so
+  // that part is still in the 256 MB memory-side cache when this pass starts.
+  for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
+    const int row = rm.M - 1 - r0;
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
     const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
     float f[8];
@@ -252,7 +255,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   float a[8], b[8], c[8];
 #pragma unroll
   for (int q = 0; q < 8; ++q) { a[q] = coefA[chunk * 8 + q]; b[q] = coefB[chunk * 8 + q]; c[q] = coefC[chunk * 8 + q]; }
-  for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+  for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
+    const int row = rm.M - 1 - r0;          // tail first: what the reduce pass read last is still cached
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
     const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
     const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);

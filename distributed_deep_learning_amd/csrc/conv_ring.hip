@@ -4,7 +4,10 @@
 // The register-staged kernel keeps ONE K-step of loads in flight and pays a full memory round trip per 64-deep
 // K-step — fatal for the short reductions of ResNet's 1x1 convs (4..32 K-steps).  Here:
 //
-//   * tile 256 pixels x BN channels x 64, 512 threads = 8 waves (4 x 2), one block per CU;
+//   * tile 256 pixels x BN channels x BK (64 or 32), 512 threads = 8 waves (4 x 2).  BK=64: 144 KiB ring, one block
+//     per CU, fewest barriers - for long reductions.  BK=32: 72 KiB ring, TWO blocks per CU, so one block's
+//     prologue / epilogue overlaps the other's MFMA loop - for the short reductions of 1x1 convs, which are otherwise
+//     latency-serialised (measured: 6x off the MFMA floor with one resident block);
 //   * both operands go global -> LDS directly (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction, no
 //     VGPRs), into a 3-stage ring, so TWO K-steps of loads are always in flight behind the one being multiplied;
 //   * zero fill (conv padding, M / N / K tails) costs nothing: lanes that must read zero use an out-of-range
@@ -16,11 +19,11 @@
 #include "common.h"
 #include "host_util.h"
 #include "conv_params.h"
+#include <cstdlib>
 
 namespace {
 
 constexpr int RBM = 256;      // pixels per tile
-constexpr int RBK = 64;       // reduction per stage
 constexpr int RNS = 3;        // ring stages
 
 // One LDS-DMA: 64 lanes x 16 bytes -> 1 KiB at `lds_byte` (wave-uniform), each lane from rsrc + voff (bytes).
@@ -29,10 +32,25 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, cha
 }
 
 // EPI bits: 1 = bias / ReLU epilogue, 2 = BN partial sums, 4 = addend (compile-time, so unused paths cost nothing)
-template <int BN, int MODE, int EPI>
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int BN, int BK, int MODE, int EPI>
 __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
-  constexpr int XBYTES = RBM * 128, WBYTES = BN * 128, STAGE = XBYTES + WBYTES;
-  constexpr int WJ = BN / 64;               // W LDS-DMA instructions per thread per stage (X: 4)
+  constexpr int RP = BK * 2;                // LDS row pitch in bytes
+  constexpr int CH = BK / 8;                // 16-byte chunks per row
+  constexpr int RW = 1024 / RP;             // rows per LDS-DMA wave-instruction
+  constexpr int XBYTES = RBM * RP, WBYTES = BN * RP, STAGE = XBYTES + WBYTES;
+  constexpr int XJ = RBM / (8 * RW);        // X LDS-DMA instructions per thread per stage
+  constexpr int WI = BN / RW;               // W wave-instructions per stage (spread over the 8 waves)
+  constexpr int WJ = (WI + 7) / 8;
+  constexpr bool WHALF = (WI < 8);          // only waves 0 .. WI-1 stage W
   constexpr int WM = 64, WN = BN / 2;       // per-wave sub-tile: 64 pixels x WN channels
   constexpr int TM = WM / 16, TN = WN / 16;
   constexpr unsigned OOB = 0xFFFFFFF0u;
@@ -55,13 +73,14 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 
   // ---- staging geometry: wave w, instruction j writes LDS rows (j*8 + w)*8 .. +7, lane -> (row lane>>3, physical
   //      chunk lane&7); the logical chunk is the same for every row of a thread.
-  const int lrow = lane >> 3;
-  const int lchunk = (lane & 7) ^ ((4 * wid + (lane >> 4)) & 7);
+  const int lrow = lane / CH;
+  const int lchunk = (BK == 64) ? ((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) : ((lane & 3) ^ ((lane >> 4) & 3));
+  const bool wwave = !WHALF || wid < WI;
 
-  int nb[4], bh[4], bw[4];
+  int nb[XJ], bh[XJ], bw[XJ];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + (j * 8 + wid) * 8 + lrow;
+  for (int j = 0; j < XJ; ++j) {
+    const int m = m0 + (j * 8 + wid) * RW + lrow;
     if (m < p.M) {
       const int n = (int)fastdiv((unsigned)m, p.div_ohw);
       const int rem = m - n * (int)p.div_ohw.d;
@@ -78,7 +97,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   bool wrow_ok[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; ++j) {
-    const int n = n0 + (j * 8 + wid) * 8 + lrow;
+    const int n = n0 + (j * 8 + wid) * RW + lrow;
     wrow_ok[j] = n < p.OC;
     wrow_off[j] = (unsigned)n * (unsigned)p.KredFull;
   }
@@ -97,7 +116,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const bool kok = kr < p.nR;
     char* const sbase = smem + stage * STAGE;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < XJ; ++j) {
       int ih, iw; bool ok;
       if (MODE == 0) {
         ih = bh[j] + r; iw = bw[j] + sx;
@@ -113,12 +132,14 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
       lds_dma16(xsrc, sbase + (j * 8 + wid) * 1024, (ok && kok) ? off : OOB);
     }
     const unsigned woff = (unsigned)((r * p.S + sx) * p.IC + kc);
+    if (wwave) {
 #pragma unroll
-    for (int j = 0; j < WJ; ++j)
-      lds_dma16(wsrc, sbase + XBYTES + (j * 8 + wid) * 1024,
-                (wrow_ok[j] && kok) ? (wrow_off[j] + woff) * 2u : OOB);
+      for (int j = 0; j < WJ; ++j)
+        lds_dma16(wsrc, sbase + XBYTES + (j * 8 + wid) * 1024,
+                  (wrow_ok[j] && kok) ? (wrow_off[j] + woff) * 2u : OOB);
+    }
     // advance the cursor by one K-step
-    kc += RBK;
+    kc += BK;
     while (kc >= p.IC) {
       kc -= p.IC;
       if (++ks_ == p.nS) { ks_ = 0; ++kr; }
@@ -131,19 +152,22 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int ksteps = (p.Kred + RBK - 1) / RBK;
+  const int ksteps = (p.Kred + BK - 1) / BK;
 
   issue(0);
   if (ksteps > 1) issue(1);
 
   int stage = 0;
   for (int t = 0; t < ksteps; ++t) {
-    // tile t has landed once at most the NEXT tile's loads (4 + WJ per thread) are still outstanding
+    // tile t has landed once at most the NEXT tile's loads (XJ + WJ per thread) are still outstanding
     if (t + 1 < ksteps) {
-      if (WJ == 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      else         asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+      if constexpr (WHALF) {
+        if (wwave) wait_vmcnt<XJ + WJ>(); else wait_vmcnt<XJ>();
+      } else {
+        wait_vmcnt<XJ + WJ>();
+      }
     } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();           // everyone's part of tile t is in LDS; everyone is done with tile t-1
     asm volatile("" ::: "memory");
@@ -151,18 +175,20 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     const char* xb = smem + stage * STAGE;
     const char* wb = xb + XBYTES;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 a[TN], b[TM];
       const int ch = ks * 4 + (lane >> 4);
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * WN + i * 16 + (lane & 15);
-        a[i] = *reinterpret_cast<const bf16x8*>(wb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        const int sw = (BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        a[i] = *reinterpret_cast<const bf16x8*>(wb + row * RP + ((ch ^ sw) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm * WM + j * 16 + (lane & 15);
-        b[j] = *reinterpret_cast<const bf16x8*>(xb + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
+        const int sw = (BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        b[j] = *reinterpret_cast<const bf16x8*>(xb + row * RP + ((ch ^ sw) << 4));
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
@@ -248,8 +274,9 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     }
   }
   if (EPI & 2) {
-    constexpr int OS_BYTES = ((RBM * OPITCH + 15) / 16) * 16;
-    float* const red = reinterpret_cast<float*>(smem + OS_BYTES);   // [RPP][2][BN]
+    static_assert(RBM * OPITCH <= RNS * STAGE && RPP * 2 * BN * 4 <= RNS * STAGE, "epilogue must fit in the ring");
+    __syncthreads();                                                // the output tile has been read out
+    float* const red = reinterpret_cast<float*>(smem);              // [RPP][2][BN], over the output tile
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
@@ -267,31 +294,40 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   }
 }
 
-template <int BN, int MODE, int EPI>
+template <int BN, int BK, int MODE, int EPI>
 int launch_ring(ConvParams& p, hipStream_t stream) {
-  constexpr int smem = RNS * (RBM + BN) * 128;
+  constexpr int smem = RNS * (RBM + BN) * BK * 2;
   static SmemAttrOnce once;
-  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, MODE, EPI>), smem);
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, BK, MODE, EPI>), smem);
   if (rc != 0) return rc;
   p.tiles_m = (p.M + RBM - 1) / RBM;
   p.tiles_n = (p.OC + BN - 1) / BN;
   const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  hipLaunchKernelGGL((conv_ring_kernel<BN, MODE, EPI>), dim3(grid), dim3(512), smem, stream, p);
+  hipLaunchKernelGGL((conv_ring_kernel<BN, BK, MODE, EPI>), dim3(grid), dim3(512), smem, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int BN>
+template <int BN, int BK>
 int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
   if (mode == 0) {
     if (p.stats != nullptr) {
       if (p.bias != nullptr || p.relu) return -6;               // statistics are taken of the raw conv output
-      return launch_ring<BN, 0, 2>(p, stream);
+      return launch_ring<BN, BK, 0, 2>(p, stream);
     }
-    if (p.bias != nullptr || p.relu) return launch_ring<BN, 0, 1>(p, stream);
-    return launch_ring<BN, 0, 0>(p, stream);
+    if (p.bias != nullptr || p.relu) return launch_ring<BN, BK, 0, 1>(p, stream);
+    return launch_ring<BN, BK, 0, 0>(p, stream);
   }
-  if (p.addend != nullptr) return launch_ring<BN, 1, 4>(p, stream);
-  return launch_ring<BN, 1, 0>(p, stream);
+  if (p.addend != nullptr) return launch_ring<BN, BK, 1, 4>(p, stream);
+  return launch_ring<BN, BK, 1, 0>(p, stream);
+}
+
+// Reduction depth per stage.  Measured over ResNet-50's layers (bench/conv_layers.py): BK=32 (two resident blocks) wins
+// everywhere except very long reductions (9 taps x 512 channels) and grids that cannot give every CU a second block.
+int ring_bk(const ConvParams& p) {
+  static const int forced = [] { const char* e = getenv("DDL_RING_BK"); return e ? atoi(e) : 0; }();
+  if (forced == 32 || forced == 64) return forced;
+  const long long tiles = (long long)((p.M + RBM - 1) / RBM) * ((p.OC + 127) / 128);
+  return (p.Kred > 2304 || tiles <= 256) ? 64 : 32;
 }
 
 }  // namespace
@@ -307,6 +343,7 @@ bool ddl_conv_ring_supported(const ConvParams& p) {
 int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream) {
   p.div_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
   p.div_ow = make_fastdiv((unsigned)p.OW);
-  if (p.OC <= 64) return dispatch_ring<64>(p, mode, stream);
-  return dispatch_ring<128>(p, mode, stream);
+  const int bk = ring_bk(p);
+  if (p.OC <= 64) return bk == 32 ? dispatch_ring<64, 32>(p, mode, stream) : dispatch_ring<64, 64>(p, mode, stream);
+  return bk == 32 ? dispatch_ring<128, 32>(p, mode, stream) : dispatch_ring<128, 64>(p, mode, stream);
 }
