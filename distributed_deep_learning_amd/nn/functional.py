@@ -12,6 +12,7 @@ from __future__ import annotations
 import torch
 
 from ..ops import kernels as K
+from ..ops import streams
 
 BF16 = torch.bfloat16
 
@@ -26,7 +27,8 @@ def _wgrad(weight, dy, x, R, S, stride, pad, cin_real):
     autograd; the arena then tells the data-parallel reducer that this tensor's gradient is ready."""
     arena = getattr(weight, "_ddl_arena", None)
     if arena is not None and cin_real == x.shape[1] and arena.grad_is_arena_view(weight):
-        K.conv2d_wgrad(dy, x, R, S, stride, pad, out=weight.grad)
+        with streams.fork(dy, x):          # side stream: overlaps the BN-backward / dgrad chain
+            K.conv2d_wgrad(dy, x, R, S, stride, pad, out=weight.grad)
         arena.notify_grad_ready(weight)
         return None
     dw = K.conv2d_wgrad(dy, x, R, S, stride, pad)

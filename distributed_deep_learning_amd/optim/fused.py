@@ -20,6 +20,7 @@ import torch
 
 from ..ops import _lib
 from ..ops import state as _state
+from ..ops import streams as _streams
 from ..parallel.arena import CHUNK, ParamArena
 
 
@@ -103,6 +104,7 @@ class _ArenaOptimizer(torch.optim.Optimizer):
     def step(self, closure=None, ranges=None, zero_grad: bool = True):
         """``ranges``: optional list of element ranges ``(lo, hi)`` (PS mode); default = whole arena."""
         loss = closure() if closure is not None else None
+        _streams.join()                 # side-stream filter gradients must have landed in the arena
         self.step_count += 1
         self._prepare()
         self._before_ranges(ranges)

@@ -199,6 +199,8 @@ class ParamArena:
 
     # ------------------------------------------------------------------ maintenance
     def zero_grad(self) -> None:
+        from ..ops import streams
+        streams.join()                 # no side-stream wgrad may still be accumulating
         self.grad.zero_()
 
     def reattach_grads(self) -> None:

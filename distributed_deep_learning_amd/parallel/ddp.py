@@ -29,6 +29,7 @@ import torch
 import torch.distributed as td
 import torch.nn as tnn
 
+from ..ops import streams
 from .arena import ParamArena
 
 
@@ -114,6 +115,10 @@ class DistributedDataParallel(tnn.Module):
             return
         self._launched[b] = True
         g = self.arena.bucket_grad(b)
+        with streams.comm_context(g):       # ordered behind the side-stream wgrads that wrote into this bucket
+            self._launch_collective(b, g)
+
+    def _launch_collective(self, b: int, g: torch.Tensor) -> None:
         if self.mode == "allreduce":
             if self.backend == "nccl":
                 h = td.all_reduce(g, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
@@ -134,6 +139,7 @@ class DistributedDataParallel(tnn.Module):
     # ------------------------------------------------------------------ step boundary
     def finish_grad_sync(self) -> None:
         """Wait for every bucket (launching those whose tensors never produced a gradient)."""
+        streams.join()
         if not self.dist or not self.require_sync:
             self._armed = False
             return
