@@ -41,6 +41,7 @@ class Config:
     seed: int = 42
     split: Sequence[float] = (0.7, 0.1, 0.2)
     samples: int = 2048                # synthetic dataset size
+    data: Optional[str] = None         # dataset path (PCB folder / CSV); default = synthetic data of the same shape
     classes: Optional[int] = None
     sync: str = "allreduce"            # gradient sync: all-reduce | ps (reduce-scatter / all-gather)
     bucket_mb: float = 32.0
@@ -94,6 +95,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--lr-gamma", dest="lr_gamma", type=float, default=0.1)
     p.add_argument("--seed", type=int, default=42)
     p.add_argument("--samples", type=int, default=2048)
+    p.add_argument("--data", default=None, help="dataset root (cnn: PCB folder) or CSV (lstm, mlp); default synthetic")
     p.add_argument("--classes", type=int, default=None)
     p.add_argument("--sync", choices=list(SYNC_MODES), default="allreduce")
     p.add_argument("--bucket-mb", dest="bucket_mb", type=float, default=32.0)

@@ -162,7 +162,10 @@ class Trainer:
 
     def _build_data(self, wl) -> None:
         cfg, info = self.cfg, self.info
-        if wl is not None:
+        if cfg.data:
+            from .data.files import open_dataset
+            ds = open_dataset(cfg.model, cfg.data, seed=cfg.seed)
+        elif wl is not None:
             ds = wl[0](cfg.samples, cfg.seed)
         elif cfg.model.startswith("vgg") or cfg.model in ("resnet18", "resnet34", "resnet50", "resnet101"):
             ds = syn.imagenet_like(cfg.samples, cfg.seed, classes=cfg.classes or 1000)
