@@ -36,6 +36,8 @@ def main() -> int:
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "lars"])
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--graph", default="off", choices=["on", "off"],
+                    help="replay the whole step as one captured hipGraph (single-process runs only)")
     a = ap.parse_args()
 
     import torch
@@ -90,6 +92,13 @@ def main() -> int:
             opt.step()
         return loss
 
+    if a.graph == "on" and info.world == 1:
+        from distributed_deep_learning_amd.utils import GraphedTrainStep
+        graphed = GraphedTrainStep(model, crit, opt, x, y, warmup=2)
+
+        def step():                           # noqa: F811 - same work, replayed from the captured graph
+            return graphed(x, y)
+
     def fence():
         if info.world > 1:
             td.barrier()
@@ -120,7 +129,7 @@ def main() -> int:
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random N(0,1) images, random-init weights)",
             "config": {"model": a.model, "global_batch": gb, "per_gpu_batch": a.batch, "image": image, "seq_len": None,
                        "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
-                       "bucket_mb": a.bucket_mb},
+                       "bucket_mb": a.bucket_mb, "hip_graph": a.graph == "on" and info.world == 1},
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S, 3)
                                              if a.model == "resnet50" and a.batch == 256 else None,
             "final_loss": round(final_loss, 4),

@@ -50,6 +50,7 @@ class Config:
     resume: Optional[str] = None
     jsonl: Optional[str] = None
     global_metrics: bool = False       # all-reduce metrics over ranks (reference reports rank 0's shard)
+    graph: bool = False                # replay the train step as one captured hipGraph (1 process, GPU, sequential)
     check_replicas: int = 0            # every k steps compare parameter checksums across ranks (debug)
     max_steps: Optional[int] = None    # stop each epoch early (smoke tests)
     master_addr: str = "127.0.0.1"
@@ -104,6 +105,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--resume", default=None)
     p.add_argument("--jsonl", default=None)
     p.add_argument("--global-metrics", dest="global_metrics", action="store_true")
+    p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
     p.add_argument("--check-replicas", dest="check_replicas", type=int, default=0)
     p.add_argument("--max-steps", dest="max_steps", type=int, default=None)
     p.add_argument("--master-addr", dest="master_addr", default="127.0.0.1")

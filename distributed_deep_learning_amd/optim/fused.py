@@ -105,18 +105,30 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         """``ranges``: optional list of element ranges ``(lo, hi)`` (PS mode); default = whole arena."""
         loss = closure() if closure is not None else None
         _streams.join()                 # side-stream filter gradients must have landed in the arena
+        self.host_prepare()
+        self.launch(ranges, zero_grad)
+        self.host_finish()
+        return loss
+
+    # The step in three parts, so a captured HIP graph (utils/graph.py) can hold ONLY the device part: the host
+    # parts run around every replay (hyper-parameters reach the kernels through the device-resident ``hyper`` array).
+    def host_prepare(self) -> None:
         self.step_count += 1
         self._prepare()
+
+    def launch(self, ranges=None, zero_grad: bool = True) -> None:
         self._before_ranges(ranges)
         for lo, hi in (ranges if ranges is not None else [(None, None)]):
             clo, chi = self._chunks(lo, hi)
             if chi > clo:
                 self._update(clo, chi, zero_grad)
-        _state.bump()
         if self.arena.shadow is not None and self._use_kernel():
             self.arena.refresh_transposes()
+
+    def host_finish(self) -> None:
+        _state.bump()
+        if self.arena.shadow is not None and self._use_kernel():
             self.arena.mark_shadow_current()
-        return loss
 
     # ---- subclass API
     def _prepare(self) -> None:

@@ -187,7 +187,32 @@ class Trainer:
         loss = self.criterion(out, y)
         return loss, self.criterion.last_correct
 
+    def _graph_step(self, x, y):
+        """The captured-graph path (``--graph``): single process, one device, fixed batch shape."""
+        cfg = self.cfg
+        ok = (cfg.graph and self.info.world == 1 and cfg.mode in ("sequential", "data") and x.is_cuda
+              and len(self.optimizers) == 1 and hasattr(self.criterion, "last_correct"))
+        if not ok:
+            return None
+        g = getattr(self, "_graphed", None)
+        if g is None:
+            if x.shape[0] != cfg.batch:
+                return None
+            from .utils.graph import GraphedTrainStep
+            y = y.to(x.device)
+            g = self._graphed = GraphedTrainStep(self.model, self.criterion, self.optimizers[0], x, y, warmup=1)
+            self.global_step += 1                      # the warm-up step trained on this batch
+            return g.warm_loss, g.warm_correct
+        if x.shape != g.x.shape:
+            return None                                # ragged last batch: eager
+        loss = g(x, y.to(x.device))
+        self.global_step += 1
+        return loss, g.correct
+
     def train_step(self, x, y):
+        out = self._graph_step(x, y)
+        if out is not None:
+            return out
         loss, correct = self._forward_loss(x, y)
         loss.backward()
         di = 0

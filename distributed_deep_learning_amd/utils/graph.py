@@ -1,0 +1,98 @@
+"""HIP-graph capture of a whole training step (forward, loss, backward, fused optimizer step).
+
+The reference wraps its models in ``torch.compile`` (``/root/reference/src/pytorch/CNN/main.py:158``) to cut
+framework overhead.  Here the hot path is pre-compiled HIP, so what is left for small models (LeNet-5, ResNet-18 on
+CIFAR, the reference's 209k-parameter DenseNet) is launch latency: hundreds of kernels of a few microseconds each.
+Capturing the step once into a hipGraph and replaying it removes the Python / launch cost of every one of them.
+
+What makes the step capturable:
+
+* every kernel of this package launches on torch's current stream (``ops/_lib.py``), allocations come from torch's
+  caching allocator (graph-private pool during capture), and nothing in the step reads a value back to the host;
+* BN slabs are self-cleaning and persistent, gradients accumulate in the flat arena, the optimizer zeroes them in
+  its own kernel: replaying the same launches on the same addresses IS the next step;
+* hyper-parameters (lr, Adam bias corrections, ...) live in a device array that the host refreshes BEFORE each
+  replay (``optimizer.host_prepare``), so schedulers keep working;
+* the side-stream wgrad fork / join (``ops/streams.py``) happens inside the capture and becomes graph edges.
+
+Not supported inside the capture: multi-process gradient collectives (use eager mode with ``world > 1``), BN with
+``momentum=None`` (its factor depends on a host counter), data-dependent control flow.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from ..nn.modules import BatchNorm2d
+from ..ops import streams
+
+
+class GraphedTrainStep:
+    """``step = GraphedTrainStep(model, criterion, optimizer, x0, y0); loss = step(x, y)``.
+
+    ``x0`` / ``y0`` fix the batch shape and dtype; later batches are copied into the static buffers.  ``loss`` and
+    ``correct`` are static device tensors that the next replay overwrites (clone them to keep a history).
+    """
+
+    def __init__(self, model, criterion, optimizer, example_x: torch.Tensor, example_y: torch.Tensor, warmup: int = 3,
+                 ddp=None):
+        if not example_x.is_cuda:
+            raise ValueError("GraphedTrainStep needs CUDA/HIP tensors")
+        if ddp is not None and ddp.dist:
+            raise NotImplementedError("graph capture with world_size > 1 is not supported: run the step eagerly")
+        for m in model.modules():
+            if isinstance(m, BatchNorm2d) and m.momentum is None:
+                raise NotImplementedError("BatchNorm with momentum=None cannot be captured")
+        self.model, self.criterion, self.optimizer = model, criterion, optimizer
+        self.bns = [m for m in model.modules() if isinstance(m, BatchNorm2d)]
+        self.x = example_x.clone()
+        self.y = example_y.clone()
+        self.loss: Optional[torch.Tensor] = None
+        self.correct: Optional[torch.Tensor] = None
+        self.graph = torch.cuda.CUDAGraph()
+        self.replays = 0
+
+        # Warm-up on a side stream (allocator pools, lazily-built slabs, autograd metadata), as eager steps.
+        s = torch.cuda.Stream(device=example_x.device)
+        s.wait_stream(torch.cuda.current_stream(example_x.device))
+        with torch.cuda.stream(s):
+            for _ in range(max(1, warmup)):
+                self.warm_loss = self._eager_step().clone()
+                wc = getattr(self.criterion, "last_correct", None)
+                self.warm_correct = wc.clone() if wc is not None else None
+        torch.cuda.current_stream(example_x.device).wait_stream(s)
+        torch.cuda.synchronize(example_x.device)
+
+        self.optimizer.host_prepare()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._forward_backward()
+            streams.join()
+            self.optimizer.launch()
+        self.correct = getattr(self.criterion, "last_correct", None)
+        # Capturing records the launches without running them: undo the host-side bookkeeping of that "step".
+        self.optimizer.step_count -= 1
+        for bn in self.bns:
+            bn._nbt_pending -= 1             # noqa: SLF001
+
+    def _forward_backward(self) -> torch.Tensor:
+        out = self.model(self.x)
+        loss = self.criterion(out, self.y)
+        loss.backward()
+        return loss.detach()
+
+    def _eager_step(self) -> torch.Tensor:
+        loss = self._forward_backward()
+        self.optimizer.step()
+        return loss
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.optimizer.host_prepare()
+        self.graph.replay()
+        for bn in self.bns:                  # host-side counters that the eager path advances inside forward()
+            bn._count_batch()                # noqa: SLF001
+        self.optimizer.host_finish()
+        self.replays += 1
+        return self.loss

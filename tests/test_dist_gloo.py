@@ -186,3 +186,37 @@ def test_external_launcher_env_is_honoured(tmp_path):
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     assert sum(1 for l in r.stdout.splitlines() if l.startswith('"test ends at ')) == 1
+
+
+# --------------------------------------------------------------------------------------------- debug ledger
+def _ledger_worker(rank, world):
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena
+    from distributed_deep_learning_amd.utils import GradLedger, replica_divergence
+    m = _mlp(3)
+    arena = ParamArena(m.named_parameters(), bucket_bytes=2048, shard_multiple=world)
+    ddp = DistributedDataParallel(m, arena=arena)
+    ledger = GradLedger(ddp)
+    x, y = _data(rank)
+    for _ in range(2):
+        ((ddp(x) - y) ** 2).mean().backward()
+        ddp.finish_grad_sync()
+        arena.zero_grad()
+    order = ledger.launch_order()
+    # a bucket launched while gradients are outstanding is a contract violation the ledger must catch
+    ddp._arm()                                           # noqa: SLF001
+    caught = False
+    try:
+        ddp._launch(len(arena.buckets) - 1)              # noqa: SLF001
+    except AssertionError:
+        caught = True
+    ddp.finish_grad_sync()
+    return {"order": order, "nb": len(arena.buckets), "caught": caught, "div": replica_divergence(ddp)}
+
+
+def test_grad_ledger_orders_buckets_and_catches_early_launch():
+    out = run_ranks(_ledger_worker, 2)
+    for o in out:
+        assert o["nb"] > 1
+        assert o["order"] == list(range(o["nb"] - 1, -1, -1))        # last bucket (first gradients) first
+        assert o["caught"]
+        assert o["div"] == 0.0

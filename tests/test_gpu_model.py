@@ -175,3 +175,58 @@ def test_trainer_gpu_cnn_reference_workload():
     cfg = Config(model="cnn", device="gpu", epochs=2, batch=32, samples=512, lr=0.01)
     hist = Trainer(cfg, printer=lines.append).setup().fit()
     assert len(lines) == 7 and hist[1]["train_loss"] < hist[0]["train_loss"] * 1.05
+
+
+def test_hip_graph_step_matches_eager_and_counts_batches():
+    """utils.GraphedTrainStep: a captured step replays to the same training trajectory as eager steps."""
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.nn.modules import BatchNorm2d
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+    from distributed_deep_learning_amd.utils import GraphedTrainStep
+    x = torch.randn(32, 3, 32, 32, device=_dev())
+    y = torch.randint(0, 10, (32,), device=_dev())
+
+    def make():
+        torch.manual_seed(0)
+        model = models.resnet18_cifar().to(_dev())
+        arena = ParamArena(model.named_parameters())
+        return model, arena, FusedSGD(arena, lr=0.02, momentum=0.9), SoftmaxCrossEntropyLoss()
+
+    warm, steps = 2, 12
+    m1, a1, o1, c1 = make()
+    eager = []
+    for _ in range(warm + steps):                        # the warm-up steps train too; the capture itself does not
+        loss = c1(m1(x), y)
+        loss.backward()
+        o1.step()
+        eager.append(float(loss.detach()))
+
+    m2, a2, o2, c2 = make()
+    step = GraphedTrainStep(m2, c2, o2, x, y, warmup=warm)
+    graphed = [float(step(x, y)) for _ in range(steps)]
+    assert o2.step_count == o1.step_count
+    ref = eager[warm:]
+    assert graphed[-1] < graphed[0]
+    for a, b in zip(graphed, ref):                       # bf16 + atomics order: trajectories agree loosely
+        assert abs(a - b) < 0.15 * max(1.0, abs(b)), (graphed, ref)
+    bn = next(m for m in m2.modules() if isinstance(m, BatchNorm2d))
+    bn.flush_counters()
+    assert int(bn.num_batches_tracked) == warm + steps
+    # a new learning rate reaches the replayed kernels through the device-resident hyper array
+    before = a2.master.clone()
+    o2.param_groups[0]["lr"] = 0.0
+    o2.flat_state["momentum"].zero_()
+    step(x, y)
+    assert torch.equal(a2.master, before)
+
+
+def test_trainer_with_hip_graph_flag():
+    from distributed_deep_learning_amd.config import Config
+    from distributed_deep_learning_amd.trainer import Trainer
+    cfg = Config(model="lenet5", device="gpu", epochs=2, batch=64, samples=640, graph=True, lr=0.05)
+    t = Trainer(cfg).setup()
+    hist = t.fit()
+    assert getattr(t, "_graphed", None) is not None and t._graphed.replays > 0
+    assert hist[1]["train_loss"] < hist[0]["train_loss"]
