@@ -277,11 +277,16 @@ static int launch_conv(const ConvParams& p, hipStream_t stream) {
 // `stats`, when not null, must hold DDL_BN_SLOTS * 2 * OC floats and be ZERO on entry (partials are accumulated
 // with atomics; ddl_bn_finalize folds the slab and leaves it zero again).
 
+// Debug: per-block phase stamps of the ring kernel (bench/conv_trace.py).  Not thread-safe; null in normal use.
+static long long* g_conv_trace = nullptr;
+extern "C" void ddl_conv_set_trace(long long* buf) { g_conv_trace = buf; }
+
 template <int MODE>
 static int launch_any(ConvParams& p, hipStream_t st) {
   // default: the 3-stage LDS-DMA ring kernel (conv_ring.hip); DDL_CONV_RING=0 selects the register-staged kernel
   static const int use_ring = [] { const char* e = getenv("DDL_CONV_RING"); return e ? atoi(e) : 1; }();
   p.mode_hint = MODE;
+  p.trace = g_conv_trace;
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
   p.tiles_m = (p.M + 127) / 128;
   static const int force64 = [] { const char* e = getenv("DDL_CONV_BN64"); return e ? atoi(e) : 0; }();

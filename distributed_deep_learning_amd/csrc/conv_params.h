@@ -19,6 +19,7 @@ struct ConvParams {
   int r0, s0, t_step, nR, nS, KredFull;
   unsigned long long in_bytes, w_bytes;
   FastDiv div_ohw, div_ow;
+  long long* trace;                       // debug: [block][4] wall-clock stamps (start, loop begin, loop end, end) or null
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 

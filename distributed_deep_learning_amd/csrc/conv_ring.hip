@@ -64,6 +64,8 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   const unsigned lid = xcd_remap(blockIdx.x, gridDim.x);
   const int tile_m = lid / p.tiles_n, tile_n = lid - tile_m * p.tiles_n;
   const int m0 = tile_m * RBM, n0 = tile_n * BN;
+  const bool tracing = p.trace != nullptr && tid == 0;
+  if (tracing) p.trace[blockIdx.x * 4 + 0] = wall_clock64();
 
   // buffer descriptors (wave-uniform: built from kernel arguments only)
   const __amdgpu_buffer_rsrc_t xsrc =
@@ -74,7 +76,11 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   // ---- staging geometry: wave w, instruction j writes LDS rows (j*8 + w)*8 .. +7, lane -> (row lane>>3, physical
   //      chunk lane&7); the logical chunk is the same for every row of a thread.
   const int lrow = lane / CH;
-  const int lchunk = (BK == 64) ? ((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) : ((lane & 3) ^ ((lane >> 4) & 3));
+  // BK=32 (64-byte rows): ds_read_b128 is served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... (MI355X
+  // guide, LDS table), i.e. rows 0-3 and 12-15 of one chunk column together with rows 4-11 of the NEXT one; the four
+  // rows that share a bank set (r, r+4, r+8, r+12) then need phys = chunk ^ {0,0,3,3}[row>>2] to land on four
+  // different 16-byte slots (PMC: SQ_LDS_BANK_CONFLICT 50 % -> 0 of LDS-active cycles).
+  const int lchunk = (BK == 64) ? ((lane & 7) ^ ((4 * wid + (lane >> 4)) & 7)) : ((lane & 3) ^ (3 * ((lane >> 5) & 1)));
   const bool wwave = !WHALF || wid < WI;
 
   int nb[XJ], bh[XJ], bw[XJ];
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   issue(0);
   if (ksteps > 1) issue(1);
 
+  if (tracing) p.trace[blockIdx.x * 4 + 1] = wall_clock64();
   int stage = 0;
   for (int t = 0; t < ksteps; ++t) {
     // tile t has landed once at most the NEXT tile's loads (XJ + WJ per thread) are still outstanding
@@ -181,13 +188,13 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
         const int row = wn * WN + i * 16 + (lane & 15);
-        const int sw = (BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        const int sw = (BK == 64) ? ((row >> 1) & 7) : (3 * ((row >> 3) & 1));
         a[i] = *reinterpret_cast<const bf16x8*>(wb + row * RP + ((ch ^ sw) << 4));
       }
 #pragma unroll
       for (int j = 0; j < TM; ++j) {
         const int row = wm * WM + j * 16 + (lane & 15);
-        const int sw = (BK == 64) ? ((row >> 1) & 7) : ((row >> 2) & 3);
+        const int sw = (BK == 64) ? ((row >> 1) & 7) : (3 * ((row >> 3) & 1));
         b[j] = *reinterpret_cast<const bf16x8*>(xb + row * RP + ((ch ^ sw) << 4));
       }
 #pragma unroll
@@ -199,6 +206,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     stage = (stage == RNS - 1) ? 0 : stage + 1;
   }
   __syncthreads();     // all fragment reads done (nothing is in flight any more): the ring becomes epilogue space
+  if (tracing) p.trace[blockIdx.x * 4 + 2] = wall_clock64();
 
   // ---- epilogue: acc -> (bias, relu) -> bf16 tile in LDS -> full-line global stores (+ addend, + BN partial sums) ----
   constexpr int OPITCH = (BN + 8) * 2;
@@ -291,6 +299,10 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
       if (n0 + col < p.OC)
         atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
     }
+  }
+  if (tracing) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include the drain of this wave's output stores
+    p.trace[blockIdx.x * 4 + 3] = wall_clock64();
   }
 }
 

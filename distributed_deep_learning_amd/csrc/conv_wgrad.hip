@@ -25,6 +25,7 @@ struct WgradParams {
   int tiles_k, tiles_n, splits, m_per_split;
   int plain;          // 1x1, stride 1, pad 0: x row index == m
   FastDiv div_pq, div_q, div_c;
+  unsigned long long dy_bytes, x_bytes;   // operand sizes (buffer descriptors of the LDS-DMA kernel)
 };
 
 // Byte offset of 16-byte chunk `ch` of row `row` inside a [rows][TW channels] bf16 tile.
@@ -36,8 +37,12 @@ __device__ __forceinline__ int tr_off(int row, int ch) {
   return row * 128 + ((ch ^ ((((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2))) << 4);
 }
 
-template <int TK, int TN>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+// G = 4-wave groups per block.  With G = 2 the two groups walk the two halves of the block's M-slice through their
+// own double buffers and meet in LDS before the atomics: the same waves and bytes in flight per CU as two
+// independent blocks, but HALF the split-M partial tiles, i.e. half the float-atomic traffic (which is ~40 % of
+// this kernel's time on the late layers: 512 blocks x 64 KiB = 32 MiB at ~1.3 TB/s = 25 us, all at the very end).
+template <int TK, int TN, int G>
+__global__ __launch_bounds__(256 * G) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int BKP = 64;                        // pixels per K-step
   constexpr int YCPR = TK / 8, XCPR = TN / 8;    // 16-byte chunks per tile row
   constexpr int YRPP = 256 / YCPR, XRPP = 256 / XCPR;
@@ -47,10 +52,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int FK = WK / 16, FN = WN / 16;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* const Ys = smem;
-  char* const Xs = smem + 2 * YBYTES;
+  const int grp = (G == 1) ? 0 : __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 8);
+  char* const Ys = smem + grp * 2 * (YBYTES + XBYTES);
+  char* const Xs = Ys + 2 * YBYTES;
 
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wid = tid >> 6;
   const int wk = wid & 1, wn = wid >> 1;
 
   // block -> (split, r, k tile, n tile), tiles fastest after the XCD remap: the tiles of one M-slice run
@@ -62,8 +68,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int split = (int)b;
   const int k0 = tk * TK, nn0 = tn * TN;
 
-  const int m_begin = split * p.m_per_split;
-  const int m_end = min(p.M, m_begin + p.m_per_split);
+  const int b_begin = split * p.m_per_split;
+  const int b_end = min(p.M, b_begin + p.m_per_split);
+  // group 0 takes the first half of the slice (rounded up to whole K-steps), group 1 the rest
+  const int half = (G == 1) ? (b_end - b_begin) : (((b_end - b_begin + 1) / 2 + BKP - 1) / BKP) * BKP;
+  const int m_begin = (grp == 0) ? b_begin : min(b_end, b_begin + half);
+  const int m_end = (grp == 0) ? min(b_end, b_begin + half) : b_end;
 
   // ---- staging assignments ----
   const int ych = tid % YCPR, yrow0 = tid / YCPR;
@@ -126,7 +136,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // inside the group lane 4q+pp addresses row q, 8 bytes at channel 4*pp of the 16-channel block.
   const int g = lane >> 4, q4 = (lane & 15) >> 2, pp4 = lane & 3;
 
-  const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
+  // every group runs the step count of the longer (first) half: block-wide barriers stay uniform, and the steps a
+  // shorter half has left over load zeros
+  const int nsteps = (half + BKP - 1) / BKP;
   if (nsteps > 0) {
     load_tile(m_begin);
     store_tile(0);
@@ -182,6 +194,198 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   if (nsteps > 0) {
     float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TN] fp32, reuses the staging buffers
 #pragma unroll
+    for (int gsel = 0; gsel < G; ++gsel) {                      // group 0 stores its tile, group 1 adds its own
+      if (grp == gsel) {
+#pragma unroll
+        for (int i = 0; i < FK; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j) {
+            const int col = wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int row = wk * WK + i * 16 + (lane >> 4) * 4 + e;
+              if (gsel == 0) Ts[row * TN + col] = acc[i][j][e];
+              else           Ts[row * TN + col] += acc[i][j][e];
+            }
+          }
+      }
+      __syncthreads();
+    }
+    constexpr int LPR = TN / 64;                                // 64-lane pieces per row
+    for (int it = wid + 4 * grp; it < TK * LPR; it += 4 * G) {
+      const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
+      const int k = k0 + row, cn = nn0 + col;
+      if (k < p.K && cn < p.SC)
+        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TN + col]);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA ring version of the same kernel.  The phase trace of the conv kernels (bench/conv_trace.py) shows that a
+// K-step costs (bytes fetched per CU) / (~70 GB/s per CU from L2), i.e. what matters is how many bytes a CU keeps in
+// flight.  The register-staged loop above has ONE 64-pixel step (32 KiB per block) in flight and spends VALU on
+// address math, zero fill and ds_write; here both operands go global -> LDS with `buffer_load ... lds` (natural
+// [pixel][channel] layout, so no transform is needed: the transposing LDS read does the rest) into a 4-stage ring of
+// 32-pixel steps, THREE steps in flight, zero fill by out-of-range buffer offsets, one counted-vmcnt barrier per
+// step.  64 KiB of LDS per block at 128x128: two blocks per CU, 96 KiB in flight per CU.
+__device__ __forceinline__ void wg_lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N < 0, "unsupported vmcnt");
+}
+
+template <int TK, int TN>
+__global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams p) {
+  constexpr int BKP = 32;                        // pixels per ring stage
+  constexpr int NS = 4;                          // ring stages (NS - 1 in flight)
+  constexpr int YROWB = TK * 2, XROWB = TN * 2;  // bytes per tile row
+  constexpr int YRW = 1024 / YROWB, XRW = 1024 / XROWB;      // rows per LDS-DMA wave-instruction (4 or 8)
+  constexpr int YJ = BKP / (4 * YRW), XJ = BKP / (4 * XRW);  // instructions per thread per stage (2 or 1)
+  constexpr int YBYTES = BKP * YROWB, XBYTES = BKP * XROWB, STAGE = YBYTES + XBYTES;
+  constexpr int WK = TK / 2, WN = TN / 2;
+  constexpr int FK = WK / 16, FN = WN / 16;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = wid & 1, wn = wid >> 1;
+
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tn = b % p.tiles_n; b /= p.tiles_n;
+  const int tk = b % p.tiles_k; b /= p.tiles_k;
+  const int r = b % p.R; b /= p.R;
+  const int split = (int)b;
+  const int k0 = tk * TK, nn0 = tn * TN;
+  const int m_begin = split * p.m_per_split;
+  const int m_end = min(p.M, m_begin + p.m_per_split);
+
+  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+
+  // ---- staging geometry.  Instruction j of wave w fills tile rows (j*4 + w)*RW .. +RW-1; lane -> (row, physical
+  //      chunk); the XOR swizzle of tr_off<> depends only on row bits that are fixed per thread (see tr_off), so the
+  //      LOGICAL chunk (= which 8 channels this lane fetches) is one constant per operand.
+  const int yrow = lane / (YROWB / 16), yphys = lane % (YROWB / 16);
+  const int xrow = lane / (XROWB / 16), xphys = lane % (XROWB / 16);
+  int ych, xch;
+  if (TK == 128) ych = yphys ^ (((yrow & 3) << 2) | (wid & 3));
+  else           ych = yphys ^ ((((yrow >> 1) & 1) << 1) | ((wid & 1) << 2));
+  if (TN == 128) xch = xphys ^ (((xrow & 3) << 2) | (wid & 3));
+  else           xch = xphys ^ ((((xrow >> 1) & 1) << 1) | ((wid & 1) << 2));
+  const bool ycol_ok = (k0 + ych * 8) < p.K;
+  const int nn = nn0 + xch * 8;
+  const bool xcol_ok = nn < p.SC;
+  const int xs = (int)fastdiv((unsigned)nn, p.div_c);
+  const int xc = nn - xs * p.C;
+  const unsigned ycol_off = (unsigned)(k0 + ych * 8);
+
+  auto issue = [&](int stage, int mbase) {
+    char* const sb = smem + stage * STAGE;
+#pragma unroll
+    for (int j = 0; j < YJ; ++j) {
+      const int m = mbase + (j * 4 + wid) * YRW + yrow;
+      const unsigned off = ((unsigned)m * (unsigned)p.K + ycol_off) * 2u;
+      wg_lds_dma16(ysrc, sb + (j * 4 + wid) * 1024, (ycol_ok && m < m_end) ? off : OOB);
+    }
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      const int m = mbase + (j * 4 + wid) * XRW + xrow;
+      unsigned off = OOB;
+      if (xcol_ok && m < m_end) {
+        if (p.plain) {
+          off = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
+        } else {
+          const unsigned n = fastdiv((unsigned)m, p.div_pq);
+          const unsigned rem = (unsigned)m - n * p.div_pq.d;
+          const unsigned pp = fastdiv(rem, p.div_q);
+          const unsigned qq = rem - pp * p.div_q.d;
+          const int ih = (int)pp * p.stride - p.pad + r;
+          const int iw = (int)qq * p.stride - p.pad + xs;
+          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
+            off = ((unsigned)((int)n * p.H * p.W + ih * p.W + iw) * (unsigned)p.C + (unsigned)xc) * 2u;
+        }
+      }
+      wg_lds_dma16(xsrc, sb + YBYTES + (j * 4 + wid) * 1024, off);
+    }
+  };
+
+  f32x4 acc[FK][FN];
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, pp4 = lane & 3;
+  const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
+  constexpr int PER = YJ + XJ;                   // loads per thread per stage
+
+  // prologue: NS-1 stages in flight (stages past the end are all-zero fills, so the counted waits stay uniform)
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s) issue(s, m_begin + s * BKP);
+
+  int stage = 0;
+  for (int t = 0; t < nsteps; ++t) {
+    wg_wait_vmcnt<(NS - 2) * PER>();             // step t has landed; the next NS-2 steps stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // refill the stage that step t-1 vacated (every wave passed the barrier, so nobody reads it any more)
+    issue(stage == 0 ? NS - 1 : stage - 1, m_begin + (t + NS - 1) * BKP);
+    const char* yb = smem + stage * STAGE;
+    const char* xb = yb + YBYTES;
+    {
+      bf16x8 a[FK], bfr[FN];
+      const int rbase = 8 * g + q4;
+#pragma unroll
+      for (int i = 0; i < FK; ++i) {
+        const int c0 = (wk * WK + i * 16) >> 3;
+        const int ch = c0 + (pp4 >> 1);
+        const int sub = (pp4 & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(yb + tr_off<TK>(rbase, ch) + sub));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(yb + tr_off<TK>(rbase + 4, ch) + sub));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int c0 = (wn * WN + j * 16) >> 3;
+        const int ch = c0 + (pp4 >> 1);
+        const int sub = (pp4 & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(xb + tr_off<TN>(rbase, ch) + sub));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(xb + tr_off<TN>(rbase + 4, ch) + sub));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        bfr[j] = __builtin_bit_cast(bf16x8, v);
+      }
+#pragma unroll
+      for (int i = 0; i < FK; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    stage = (stage == NS - 1) ? 0 : stage + 1;
+  }
+  wg_wait_vmcnt<0>();                            // the trailing zero fills must land before the ring is reused
+  __syncthreads();
+
+  if (nsteps > 0) {
+    float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TN] fp32, reuses the ring
+    static_assert(TK * TN * 4 <= NS * STAGE, "epilogue tile must fit in the ring");
+#pragma unroll
     for (int i = 0; i < FK; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
@@ -193,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         }
       }
     __syncthreads();
-    constexpr int LPR = TN / 64;                                // 64-lane pieces per row
+    constexpr int LPR = TN / 64;
     for (int it = wid; it < TK * LPR; it += 4) {
       const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
       const int k = k0 + row, cn = nn0 + col;
@@ -201,6 +405,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TN + col]);
     }
   }
+}
+
+template <int TK, int TN, int G>
+static int launch_wgrad_g(WgradParams& p, hipStream_t stream, int smem, unsigned grid) {
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<TK, TN, G>), smem);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL((conv_wgrad_kernel<TK, TN, G>), dim3(grid), dim3(256 * G), smem, stream, p);
+  return (int)hipGetLastError();
 }
 
 template <int TK, int TN>
@@ -211,25 +424,39 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   // One full round of resident blocks (2 per CU x 256 CUs), never more: a grid of 1.1 rounds runs as long as 2,
   // and every extra split adds a tile of fp32 atomic traffic (~1.3 TB/s chip-wide).  Splits are never shorter
   // than 256 pixels (4 K-steps).
-  const int smem = 2 * 64 * (TK + TN) * 2;
+  // DDL_WGRAD_RING=1 selects the LDS-DMA ring variant (measured slower on ResNet-50: 5.74 vs 5.17 ms per step).
+  static const int use_ring = [] { const char* e = getenv("DDL_WGRAD_RING"); return e ? atoi(e) : 0; }();
+  static const int groups = [] { const char* e = getenv("DDL_WGRAD_GROUPS"); return e ? atoi(e) : 2; }();
+  const bool ring = use_ring && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull;
+  // Measured per layer (bench/conv_layers.py, B=256): pairing the groups pays where the atomic tail dominates, i.e. the
+  // plain 1x1 convs with a short reduction per tile (-8..-20 %); 3x3 and the big first-in-stage 1x1 layers lose to the
+  // 8-wave barriers (+3..+50 %), so they keep independent 4-wave blocks.
+  const double flops = 2.0 * (double)p.M * (double)p.K * (double)p.C * (double)p.R * (double)p.S;
+  const int G = (!ring && groups == 2 && p.plain && flops < 40e9) ? 2 : 1;
+  const int smem = ring ? 4 * 32 * (TK + TN) * 2 : G * 2 * 64 * (TK + TN) * 2;
   static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
-  const int per_cu = (160 * 1024) / smem < 4 ? (160 * 1024) / smem : 4;      // LDS- and register-limited residency
+  const int max_cu = 4 / G;                                                   // 16 waves per CU at most
+  const int per_cu = (160 * 1024) / smem < max_cu ? (160 * 1024) / smem : max_cu;   // LDS- and register-limited residency
   const long long capacity = cap_env > 0 ? cap_env : 256 * per_cu;
   long long splits = capacity / tiles;
   const long long max_splits = (p.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   long long mps = (p.M + splits - 1) / splits;
-  mps = ((mps + 63) / 64) * 64;
+  mps = ((mps + 64 * G - 1) / (64 * G)) * (64 * G);
   splits = (p.M + mps - 1) / mps;
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
-  static SmemAttrOnce once;
-  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<TK, TN>), smem);
-  if (rc != 0) return rc;
   const unsigned grid = (unsigned)(tiles * splits);
-  hipLaunchKernelGGL((conv_wgrad_kernel<TK, TN>), dim3(grid), dim3(256), smem, stream, p);
-  return (int)hipGetLastError();
+  if (ring) {
+    static SmemAttrOnce once_ring;
+    const int rc = once_ring.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN>), smem);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN>), dim3(grid), dim3(256), smem, stream, p);
+    return (int)hipGetLastError();
+  }
+  if (G == 2) return launch_wgrad_g<TK, TN, 2>(p, stream, smem, grid);
+  return launch_wgrad_g<TK, TN, 1>(p, stream, smem, grid);
 }
 
 // dw (fp32, [K][R][S][C]) must be zero on entry: the kernel accumulates with atomics.
@@ -246,6 +473,8 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
   p.div_pq = make_fastdiv((unsigned)(P * Q));
   p.div_q = make_fastdiv((unsigned)Q);
   p.div_c = make_fastdiv((unsigned)C);
+  p.dy_bytes = (unsigned long long)M * K * 2ull;
+  p.x_bytes = (unsigned long long)N * H * W * C * 2ull;
   hipStream_t st = (hipStream_t)stream;
   const bool k64 = K <= 64, n64 = p.SC <= 64 || (p.SC % 128 != 0 && p.SC % 64 == 0 && p.SC < 512);
   if (k64 && n64) return launch_wgrad<64, 64>(p, st);
