@@ -229,6 +229,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         float f[8], a[8];
         unpack8(v, f);
         unpack8(av, a);
+        if (p.addend_mask != nullptr) {          // addend = (upstream gradient) x (ReLU mask of the block output)
+          const unsigned mk = p.addend_mask[opix * (size_t)(p.OC >> 3) + (size_t)(ncol >> 3)];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] = ((mk >> q) & 1u) ? a[q] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) f[q] += a[q];
         vo = pack8(f);
@@ -299,7 +304,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
 }
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
-                              const void* addend, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              const void* addend, const void* addend_mask, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
@@ -308,6 +313,8 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   ConvParams p;
   p.in = (const bf16_t*)in; p.wmat = (const bf16_t*)wmat; p.out = (bf16_t*)out; p.bias = bias; p.stats = stats;
   p.addend = (const bf16_t*)addend;
+  p.addend_mask = (const unsigned char*)addend_mask;
+  if (addend_mask != nullptr && addend == nullptr) return -7;
   if (addend != nullptr && stats != nullptr) return -5;      // statistics are taken before the addend
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;

@@ -8,6 +8,7 @@ struct ConvParams {
   bf16_t* out;
   const float* bias;   // optional [OC]
   const bf16_t* addend; // optional, same shape as out: out = conv + addend (gradient accumulation fused in dgrad)
+  const unsigned char* addend_mask; // optional 1-bit-per-element mask on the addend ([pixels][OC/8] bytes, BN-apply layout)
   float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
   int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;
   int M, Kred;

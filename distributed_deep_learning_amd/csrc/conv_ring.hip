@@ -268,6 +268,11 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         float f[8], a[8];
         unpack8(v, f);
         unpack8(av, a);
+        if (p.addend_mask != nullptr) {          // addend = (upstream gradient) x (ReLU mask of the block output)
+          const unsigned mk = p.addend_mask[opix * (size_t)(p.OC >> 3) + (size_t)(ncol >> 3)];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a[q] = ((mk >> q) & 1u) ? a[q] : 0.f;
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) f[q] += a[q];
         vo = pack8(f);

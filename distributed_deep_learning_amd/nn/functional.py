@@ -138,14 +138,19 @@ class ResidualBlock(torch.autograd.Function):
         metas = ctx.metas
         grads = {}
 
-        def back(idx, dy, need_dx, addend=None):
+        def back(idx, dy, need_dx, addend=None, addend_mask=None, relu_mask=None, want_dres=False):
+            """BN(+ReLU) backward -> dgrad (+ addend) -> wgrad of unit ``idx``.  ``relu_mask`` overrides the unit's
+            own activation: the unit then sees ``dy * mask`` (used to push the block-output ReLU into the shortcut)."""
             inp, y_conv, mask, vec, crsk = saved[5 * idx:5 * idx + 5]
-            conv, bn, relu, has_res, slab = metas[idx]
+            conv, bn, relu, _has_res, slab = metas[idx]
+            if relu_mask is not None:
+                relu, mask = True, relu_mask
             dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, vec[0], vec[1],
-                                                 relu, has_res, slab)
+                                                 relu, want_dres, slab)
             dx = None
             if need_dx:
-                dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend)
+                dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend,
+                                    addend_mask=addend_mask)
             R, S = conv.kernel_size
             dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
             grads[idx] = (dw, dgamma, dbeta)
@@ -155,25 +160,27 @@ class ResidualBlock(torch.autograd.Function):
         first_main = 1 if ctx.has_ds else 0
         n_units = len(metas)
         need_x = ctx.needs_input_grad[0]
-        d = dout
-        dres = None
-        for idx in range(n_units - 1, first_main, -1):          # main path, last unit first
-            d, r = back(idx, d, True)
-            if r is not None:
-                dres = r
-        if n_units - 1 == first_main:                            # single main unit (not used by ResNet)
-            pass
-        # first main unit: its dgrad epilogue also adds the shortcut's gradient
-        if ctx.has_ds:
-            dshort, _ = back(0, dres, need_x)                    # projection shortcut: gradient w.r.t. the block input
-        else:
-            dshort = dres
-        if n_units - 1 > first_main:
-            dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None)
-        else:                                                    # degenerate: the only main unit carries the residual
-            dx, r = back(first_main, d, need_x)
+        last = n_units - 1
+        out_mask = saved[5 * last + 2]                # ReLU mask of the block output
+        if last > first_main:
+            # The shortcut's gradient is dout * relu'(out).  It is never written: the projection's BN backward and the
+            # first conv's dgrad epilogue apply the block-output mask to ``dout`` themselves.
+            d, _ = back(last, dout, True)
+            for idx in range(last - 1, first_main, -1):
+                d, _ = back(idx, d, True)
+            if ctx.has_ds:
+                dshort, _ = back(0, dout, need_x, relu_mask=out_mask)
+                dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None)
+            else:
+                dx, _ = back(first_main, d, need_x, addend=dout if need_x else None,
+                             addend_mask=out_mask if need_x else None)
+        else:                                         # degenerate: the only main unit carries the residual
+            dx, r = back(first_main, dout, need_x, want_dres=True)
+            if ctx.has_ds:
+                dshort, _ = back(0, r, need_x)
+                r = dshort
             if need_x and r is not None:
-                dx = K.add(dx, r if not ctx.has_ds else dshort)
+                dx = K.add(dx, r)
         out = []
         for idx in range(n_units):
             out.extend(grads[idx])

@@ -74,6 +74,34 @@ def test_conv_fwd_dgrad_wgrad(case):
     _close(dw, dw_ref, rtol=1e-2, atol=1e-2 * scale, what="conv wgrad")
 
 
+@pytest.mark.parametrize("case", [(2, 64, 14, 14, 256, 1, 1, 0), (3, 256, 9, 9, 64, 1, 1, 0), (2, 128, 16, 16, 128, 3, 1, 1),
+                                  (2, 64, 16, 16, 64, 3, 2, 1)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_conv_dgrad_addend_epilogue(case, masked, monkeypatch):
+    """dx = dgrad(dy) + addend [* relu-mask bits]: the fused residual-gradient accumulation (both conv kernels)."""
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    N, C, H, W, Kc, R, stride, pad = case
+    w = (torch.randn((Kc, C, R, R), generator=torch.Generator().manual_seed(2)) / (C * R * R) ** 0.5)
+    w = w.to(_dev()).contiguous(memory_format=CL)
+    w_krsc, w_crsk = K.filter_repack(w)
+    wq = w_krsc.permute(0, 3, 1, 2).float()
+    P, Q = K.conv_out_size(H, R, stride, pad), K.conv_out_size(W, R, stride, pad)
+    dy = _rand_act((N, Kc, P, Q), 3)
+    addend = _rand_act((N, C, H, W), 4)
+    mask = None
+    keep = torch.ones((N, C, H, W), device=_dev())
+    if masked:
+        # the mask in BN-apply layout: produced by the real kernel from a random pre-activation
+        pre = _rand_act((N, C, H, W), 5)
+        one, zero = torch.ones(C, device=_dev()), torch.zeros(C, device=_dev())
+        yact, mask = K.bn_apply(pre, one, zero, relu=True, want_mask=True)
+        keep = (yact.float() > 0).float()
+    dx = K.conv2d_dgrad(dy, w_crsk, (H, W), stride, pad, addend=addend, addend_mask=mask)
+    ref = torch.nn.grad.conv2d_input((N, C, H, W), wq, dy.float(), stride, pad) + addend.float() * keep
+    _close(dx, ref, what="dgrad + addend")
+
+
 def test_conv_bias_relu_epilogue():
     from distributed_deep_learning_amd.ops import kernels as K
 
