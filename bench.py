@@ -36,6 +36,8 @@ def main() -> int:
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "lars"])
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--image", type=int, default=224)
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="diagnostic: issue the (identity) RCCL collectives of the DP reducer even on one GPU")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay the whole step as one captured hipGraph (single-process runs only)")
     a = ap.parse_args()
@@ -58,15 +60,15 @@ def main() -> int:
         print("bench.py: no GPU visible", file=sys.stderr)
         return 2
     dev = torch.device(f"cuda:{info.local_rank}")
-    ddist.init(info, dev)
+    ddist.init(info, dev, force=a.force_collectives)
     torch.manual_seed(1234)
 
     classes = 10 if a.model == "resnet18_cifar" else 1000
     image = 32 if a.model == "resnet18_cifar" else a.image
     model = models.build(a.model).to(dev)
     ddp = None
-    if info.world > 1:
-        ddp = DistributedDataParallel(model, bucket_mb=a.bucket_mb, mode=a.sync)
+    if info.world > 1 or a.force_collectives:
+        ddp = DistributedDataParallel(model, bucket_mb=a.bucket_mb, mode=a.sync, force_collectives=a.force_collectives)
         arena = ddp.arena
     else:
         arena = ParamArena(model.named_parameters(), bucket_bytes=int(a.bucket_mb * 2**20))
@@ -110,6 +112,7 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
+    host_dt = time.perf_counter() - t0        # time to ENQUEUE the steps (informational: CPU-bound if ~= ms_per_step)
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -132,7 +135,7 @@ def main() -> int:
                        "bucket_mb": a.bucket_mb, "hip_graph": a.graph == "on" and info.world == 1},
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S, 3)
                                              if a.model == "resnet50" and a.batch == 256 else None,
-            "final_loss": round(final_loss, 4),
+            "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(1e3 * host_dt / a.steps, 3),
             "note": "reference publishes no numbers (BASELINE.md); comparator = stock PyTorch-ROCm measured on the same MI355X",
         }
         print(json.dumps(rec), flush=True)

@@ -49,13 +49,13 @@ def backend_for(device: torch.device) -> str:
 
 
 def init(info: Optional[RankInfo] = None, device: Optional[torch.device] = None, timeout_s: float = 600.0,
-         master_addr: Optional[str] = None, master_port: Optional[int] = None) -> RankInfo:
+         master_addr: Optional[str] = None, master_port: Optional[int] = None, force: bool = False) -> RankInfo:
     """Initialise the default process group (no-op for world == 1).  Binds ``cuda:{local_rank}`` first so RCCL
     opens its communicator on the right GPU (the reference leaves every non-``data`` rank on ``cuda:0``)."""
     info = info or discover()
     if device is not None and device.type == "cuda":
         torch.cuda.set_device(device)
-    if info.world <= 1 or td.is_initialized():
+    if (info.world <= 1 and not force) or td.is_initialized():     # force: a 1-rank group (diagnostics / tests)
         return info
     if master_addr is not None:
         os.environ["MASTER_ADDR"] = master_addr

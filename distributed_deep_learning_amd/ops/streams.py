@@ -43,7 +43,12 @@ def set_enabled(flag: bool) -> None:
 def _stream(index: int) -> torch.cuda.Stream:
     s = _side.get(index)
     if s is None:
-        s = torch.cuda.Stream(device=index)
+        # A stream of a DIFFERENT priority class gets a hardware queue of its own.  Normal-priority streams are dealt
+        # round-robin onto GPU_MAX_HW_QUEUES (4) queues, and once RCCL has created its streams the side stream can
+        # land on the main stream's queue, where it overlaps nothing (measured: rocprof queue ids, kernel-time sum ==
+        # busy time).  DDL_WGRAD_STREAM_PRIORITY: -1 high (default), 0 normal.
+        prio = int(os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "-1"))
+        s = torch.cuda.Stream(device=index, priority=prio)
         _side[index] = s
     return s
 

@@ -36,14 +36,17 @@ from .arena import ParamArena
 class DistributedDataParallel(tnn.Module):
     def __init__(self, module: tnn.Module, bucket_mb: float = 32.0, mode: str = "allreduce",
                  arena: Optional[ParamArena] = None, process_group=None, broadcast_buffers: bool = True,
-                 first_bucket_mb: Optional[float] = None):
+                 first_bucket_mb: Optional[float] = None, force_collectives: bool = False):
+        """``force_collectives``: issue the (identity) collectives even with a world size of 1 — lets a one-GPU box
+        drive the real RCCL path (async works, comm-stream ordering, reduce-scatter / all-gather shapes)."""
         super().__init__()
         if mode not in ("allreduce", "ps"):
             raise ValueError("mode must be 'allreduce' or 'ps'")
         self.module = module
         self.mode = mode
         self.pg = process_group
-        self.dist = td.is_available() and td.is_initialized() and td.get_world_size(self.pg) > 1
+        self.dist = (td.is_available() and td.is_initialized()
+                     and (td.get_world_size(self.pg) > 1 or force_collectives))
         self.world = td.get_world_size(self.pg) if self.dist else 1
         self.rank = td.get_rank(self.pg) if self.dist else 0
         if arena is None:

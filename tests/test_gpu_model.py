@@ -163,6 +163,30 @@ def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
             ddp.step(opt)
             l0 = l0 or float(loss.detach())
         assert float(loss.detach()) < l0
+
+        # The same loop with the collectives really issued over RCCL (identities at world 1): bucketed async
+        # all-reduce launched from the gradient-ready notifications behind the side-stream wgrads, and the PS mode's
+        # reduce-scatter -> sharded step -> all-gather.  Both must train exactly like the pass-through reducer.
+        def run(mode, force):
+            torch.manual_seed(0)
+            m = models.resnet18_cifar().to(_dev())
+            d = DistributedDataParallel(m, bucket_mb=2, mode=mode, force_collectives=force)
+            assert d.dist == force and len(d.arena.buckets) > 3
+            o = FusedSGD(d.arena, lr=0.05, momentum=0.9)
+            d.attach(o)
+            ls = []
+            for _ in range(6):
+                loss = crit(d(x), y)
+                loss.backward()
+                d.step(o)
+                ls.append(float(loss.detach()))
+            return ls, d.arena.master.clone()
+
+        base, wb = run("allreduce", False)
+        for mode in ("allreduce", "ps"):
+            ls, w = run(mode, True)
+            assert all(abs(a - b) < 0.05 * max(1.0, abs(b)) for a, b in zip(ls, base)), (mode, ls, base)
+            assert (w - wb).abs().max().item() < 0.05 * wb.abs().max().item()
     finally:
         td.destroy_process_group()
 
@@ -230,3 +254,4 @@ def test_trainer_with_hip_graph_flag():
     hist = t.fit()
     assert getattr(t, "_graphed", None) is not None and t._graphed.replays > 0
     assert hist[1]["train_loss"] < hist[0]["train_loss"]
+
