@@ -112,7 +112,6 @@ def main() -> int:
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
-    host_dt = time.perf_counter() - t0        # time to ENQUEUE the steps (informational: CPU-bound if ~= ms_per_step)
     fence()
     dt = time.perf_counter() - t0
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -135,7 +134,7 @@ def main() -> int:
                        "bucket_mb": a.bucket_mb, "hip_graph": a.graph == "on" and info.world == 1},
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S, 3)
                                              if a.model == "resnet50" and a.batch == 256 else None,
-            "final_loss": round(final_loss, 4), "host_enqueue_ms_per_step": round(1e3 * host_dt / a.steps, 3),
+            "final_loss": round(final_loss, 4),
             "note": "reference publishes no numbers (BASELINE.md); comparator = stock PyTorch-ROCm measured on the same MI355X",
         }
         print(json.dumps(rec), flush=True)

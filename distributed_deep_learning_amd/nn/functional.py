@@ -114,7 +114,8 @@ class ResidualBlock(torch.autograd.Function):
             n, _, p_, q_ = y_conv.shape
             vec = K.bn_finalize(stats, n * p_ * q_, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn._momentum(), bn.eps)
-            out, mask = K.bn_apply(y_conv, vec[2], vec[3], residual=residual, relu=relu, want_mask=True)
+            rows = K.vec_rows(vec)
+            out, mask = K.bn_apply(y_conv, rows[2], rows[3], residual=residual, relu=relu, want_mask=True)
             saved.extend([inp, y_conv, mask, vec, crsk])
             metas.append((conv, bn, relu, residual is not None, slabs[1]))
             return out
@@ -145,7 +146,8 @@ class ResidualBlock(torch.autograd.Function):
             conv, bn, relu, _has_res, slab = metas[idx]
             if relu_mask is not None:
                 relu, mask = True, relu_mask
-            dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, vec[0], vec[1],
+            rows = K.vec_rows(vec)
+            dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
                                                  relu, want_dres, slab)
             dx = None
             if need_dx:

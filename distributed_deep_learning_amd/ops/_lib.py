@@ -85,12 +85,24 @@ def require():
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)       # noqa: SLF001
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)                 # noqa: SLF001
+
+
 def stream_ptr() -> int:
+    """hipStream_t of torch's current stream.  ``torch.cuda.current_stream()`` builds a Python Stream object and
+    costs ~9 us per call (1.5 ms of host time per ResNet-50 step); the raw accessor is ~20x cheaper."""
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
 
 
-def ptr(t: torch.Tensor | None):
-    return None if t is None else t.data_ptr()
+def ptr(t):
+    """Device address of a tensor; ``None`` and raw integer addresses pass through (hot paths compute sub-buffer
+    addresses by arithmetic instead of creating tensor views)."""
+    if t is None or isinstance(t, int):
+        return t
+    return t.data_ptr()
 
 
 class HipKernelError(RuntimeError):

@@ -57,7 +57,8 @@ def filter_repack(w: torch.Tensor, want_copy: bool = True):
 def new_slab(channels: int, device) -> torch.Tensor:
     """A zeroed ``[slots, 2, C]`` reduction slab.  Slabs are self-cleaning (the finalize kernels re-zero them), so
     one can be kept per layer and reused every step without a memset."""
-    return torch.zeros((_lib.bn_slots(), 2, channels), dtype=torch.float32, device=device)
+    # two extra rows: scratch for the three per-channel coefficient vectors of the backward pass (never folded)
+    return torch.zeros((_lib.bn_slots() + 2, 2, channels), dtype=torch.float32, device=device)
 
 
 def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=False, slab=None):
@@ -160,10 +161,18 @@ def bn_finalize(slab, count, gamma, beta, running_mean, running_var, momentum, e
     lib = _lib.require()
     Cc = slab.shape[-1]
     vec = torch.empty((4, Cc), dtype=torch.float32, device=slab.device)
-    check(lib.ddl_bn_finalize(ptr(slab), slab.shape[0], Cc, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
-                              ptr(running_var), float(momentum), float(eps), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
-                              ptr(vec[3]), stream_ptr()), "bn_finalize")
+    v0, row = vec.data_ptr(), 4 * Cc
+    check(lib.ddl_bn_finalize(ptr(slab), _lib.bn_slots(), Cc, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                              ptr(running_var), float(momentum), float(eps), v0, v0 + row, v0 + 2 * row, v0 + 3 * row,
+                              stream_ptr()), "bn_finalize")
     return vec
+
+
+def vec_rows(vec):
+    """Addresses of the four rows (mean, invstd, scale, shift) of a :func:`bn_finalize` result — accepted wherever a
+    per-channel fp32 vector is expected, without creating tensor views on the hot path."""
+    v0, row = vec.data_ptr(), 4 * vec.shape[1]
+    return v0, v0 + row, v0 + 2 * row, v0 + 3 * row
 
 
 def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False):
@@ -205,7 +214,7 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     if slab is None:
         slab = new_slab(Cc, x.device)
-    coef = torch.empty((3, Cc), dtype=torch.float32, device=x.device)
+    coef = slab.data_ptr() + _lib.bn_slots() * 2 * Cc * 4        # the slab's scratch rows
     check(lib.ddl_bn_backward(ptr(dy), ptr(mask) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
                               int(grad_out is not None), stream_ptr()), "bn_backward")
