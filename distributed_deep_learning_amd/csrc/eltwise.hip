@@ -69,9 +69,13 @@ __global__ __launch_bounds__(256) void add_kernel(const bf16_t* __restrict__ a, 
   }
 }
 
-// Per-channel bias gradient: db[c] = sum_m dy[m][c]  (dy bf16 [M][C], db fp32, accumulated with atomics; zeroed here)
-__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, float* __restrict__ db, int M,
-                                                        int C, int c8) {
+// Per-channel bias gradient: db[c] += sum_m g[m][c]  (bf16 [M][C] in, fp32 atomics out).
+// GATE: g = dy * [y > 0] is formed on the fly AND written to dx — ReLU backward and bias gradient in ONE pass over
+// the activation gradient (VGG-style conv+bias+ReLU blocks: saves a full re-read of the gated gradient).
+template <bool GATE>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                        bf16_t* __restrict__ dx, float* __restrict__ db, int M, int C,
+                                                        int c8) {
   __shared__ float red[256 * 8];
   const int cpb = c8 <= 256 ? c8 : 256;
   const int rp = 256 / cpb;
@@ -82,9 +86,18 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
   for (int e = 0; e < 8; ++e) acc[e] = 0.f;
   if (rg < rp && chunk < c8) {
     for (int row = blockIdx.x * rp + rg; row < M; row += gridDim.x * rp) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(dy + (size_t)row * C + (size_t)chunk * 8);
+      const size_t off = (size_t)row * C + (size_t)chunk * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(dy + off);
       float f[8];
       unpack8(v, f);
+      if (GATE) {
+        const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
+        float yf[8];
+        unpack8(yv, yf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = yf[e] > 0.f ? f[e] : 0.f;
+        *reinterpret_cast<u32x4*>(dx + off) = pack8(f);
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += f[e];
     }
@@ -223,18 +236,36 @@ extern "C" int ddl_add(const void* a, const void* b, void* out, long long n, int
                                (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n / 8);
   return (int)hipGetLastError();
 }
-extern "C" int ddl_bias_grad(const void* dy, float* db, int M, int C, void* stream) {
+static int launch_bias_grad(const void* dy, const void* y, void* dx, float* db, int M, int C, int accumulate,
+                            hipStream_t st) {
   if (C % 8 != 0 || M <= 0) return -1;
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
-  if (e != hipSuccess) return (int)e;
+  if (!accumulate) {
+    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+    if (e != hipSuccess) return (int)e;
+  }
   const int c8 = C / 8, cpb = c8 <= 256 ? c8 : 256, rp = 256 / cpb;
   const int gy = (c8 + cpb - 1) / cpb;
   long long gx = ((long long)M + rp * 8 - 1) / (rp * 8);
   if (gx < 1) gx = 1;
-  if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(bias_grad_kernel, dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy, db, M, C, c8);
+  const long long cap = y != nullptr ? 2048 : 1024;
+  if (gx > cap) gx = cap;
+  if (y != nullptr)
+    hipLaunchKernelGGL((bias_grad_kernel<true>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)y, (bf16_t*)dx, db, M, C, c8);
+  else
+    hipLaunchKernelGGL((bias_grad_kernel<false>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)nullptr, (bf16_t*)nullptr, db, M, C, c8);
   return (int)hipGetLastError();
+}
+extern "C" int ddl_bias_grad(const void* dy, float* db, int M, int C, void* stream) {
+  return launch_bias_grad(dy, nullptr, nullptr, db, M, C, 0, (hipStream_t)stream);
+}
+// dx = dy * [y > 0] and db (+)= column sums of dx, one pass.  accumulate: add into db (arena gradient) instead of
+// overwriting it.
+extern "C" int ddl_relu_bwd_bias_grad(const void* dy, const void* y, void* dx, float* db, int M, int C,
+                                      int accumulate, void* stream) {
+  if (y == nullptr || dx == nullptr) return -2;
+  return launch_bias_grad(dy, y, dx, db, M, C, accumulate, (hipStream_t)stream);
 }
 // in_is_f32: 1 -> `in` is fp32 (master weights), 0 -> bf16.  copy may be null.
 extern "C" int ddl_filter_repack(const void* in, int in_is_f32, void* copy, void* outT, int K, int RS, int C,

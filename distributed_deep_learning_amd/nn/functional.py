@@ -200,6 +200,7 @@ class ConvBiasAct(torch.autograd.Function):
         ctx.save_for_backward(x, y if relu else None, w_crsk)
         ctx.geom = (stride, pad, relu, bias is not None, w_krsc.shape[1], w_krsc.shape[2], cin_real)
         ctx.weight = weight
+        ctx.bias = bias
         return y
 
     @staticmethod
@@ -207,9 +208,19 @@ class ConvBiasAct(torch.autograd.Function):
         x, y, w_crsk = ctx.saved_tensors
         stride, pad, relu, has_bias, R, S, cin_real = ctx.geom
         dy = K.nhwc(_bf16(dy))
-        if relu:
-            dy = K.relu_bwd(dy, y)
-        db = K.bias_grad(dy) if has_bias else None
+        db = None
+        if relu and has_bias:                       # ReLU backward + bias gradient in one pass, straight into the arena
+            bias = ctx.bias
+            arena = getattr(bias, "_ddl_arena", None)
+            if arena is not None and arena.grad_is_arena_view(bias):
+                dy, _ = K.relu_bwd_bias_grad(dy, y, grad_out=bias.grad)
+                arena.notify_grad_ready(bias)
+            else:
+                dy, db = K.relu_bwd_bias_grad(dy, y)
+        else:
+            if relu:
+                dy = K.relu_bwd(dy, y)
+            db = K.bias_grad(dy) if has_bias else None
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w_crsk, tuple(x.shape[2:]), stride, pad)

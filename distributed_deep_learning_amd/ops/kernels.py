@@ -332,6 +332,27 @@ def add(a, b, relu=False):
     return out
 
 
+def relu_bwd_bias_grad(dy, y, grad_out=None):
+    """One pass: ``dx = dy * [y > 0]`` and the per-channel sums of ``dx`` (the bias gradient of a conv+bias+ReLU block).
+    ``grad_out``: contiguous fp32 ``[C]`` tensor to ACCUMULATE into (arena gradient view); else a fresh tensor."""
+    lib = _lib.require()
+    _chk_act(dy, "relu_bwd_bias_grad")
+    dy, y = nhwc(dy), nhwc(y)
+    if y.shape != dy.shape:
+        raise ValueError("relu_bwd_bias_grad: shape mismatch")
+    N, Cc, H, W = dy.shape
+    dx = torch.empty_like(dy, memory_format=CL)
+    if grad_out is not None:
+        if not (grad_out.is_contiguous() and grad_out.numel() == Cc and grad_out.dtype == torch.float32):
+            raise ValueError("relu_bwd_bias_grad: grad_out must be a contiguous fp32 [C] tensor")
+        db = grad_out
+    else:
+        db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+    check(lib.ddl_relu_bwd_bias_grad(ptr(dy), ptr(y), ptr(dx), ptr(db), N * H * W, Cc, int(grad_out is not None),
+                                     stream_ptr()), "relu_bwd_bias_grad")
+    return dx, db
+
+
 def bias_grad(dy):
     """dy bf16 NHWC ``[N,K,P,Q]`` (or ``[M,K]``) -> fp32 ``[K]``."""
     lib = _lib.require()

@@ -240,3 +240,18 @@ def test_softmax_xent(dtype, B, V):
     out2, dz2 = K.softmax_xent(z, probs)
     assert abs(out2[0].item() - ref.item()) < 2e-3 * max(1.0, abs(ref.item()))
     _close(dz2, zf.grad, rtol=2e-2, atol=1e-4, what="xent grad (prob targets)")
+
+
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (2, 512, 7, 9), (3, 4096, 2, 2)])
+def test_relu_bwd_bias_grad_fused(shape):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    dy, y = _rand_act(shape, 11), _rand_act(shape, 12)
+    dx, db = K.relu_bwd_bias_grad(dy, y)
+    ref = dy.float() * (y.float() > 0)
+    assert torch.equal(dx.float(), ref)
+    _close(db, ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="bias grad")
+    acc = torch.ones(shape[1], device=_dev())
+    dx2, out = K.relu_bwd_bias_grad(dy, y, grad_out=acc)
+    assert out is acc and torch.equal(dx2, dx)
+    _close(acc, 1.0 + ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="bias grad accumulate")
