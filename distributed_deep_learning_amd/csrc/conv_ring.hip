@@ -338,13 +338,14 @@ int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
   return launch_ring<BN, BK, 1, 0>(p, stream);
 }
 
-// Reduction depth per stage.  Measured over ResNet-50's layers (bench/conv_layers.py): BK=32 (two resident blocks) wins
-// everywhere except very long reductions (9 taps x 512 channels) and grids that cannot give every CU a second block.
+// Reduction depth per stage.  Measured over ResNet-50's layers at per-GPU batch 256 and 512 (bench/conv_layers.py):
+// BK=32 (two resident blocks per CU) wins whenever the grid can give every CU a second block, for short and long
+// reductions alike; a grid of at most one block per CU runs faster with the deeper BK=64 stages (fewer barriers).
 int ring_bk(const ConvParams& p) {
   static const int forced = [] { const char* e = getenv("DDL_RING_BK"); return e ? atoi(e) : 0; }();
   if (forced == 32 || forced == 64) return forced;
   const long long tiles = (long long)((p.M + RBM - 1) / RBM) * ((p.OC + 127) / 128);
-  return (p.Kred > 2304 || tiles <= 256) ? 64 : 32;
+  return tiles <= 256 ? 64 : 32;
 }
 
 }  // namespace
