@@ -172,12 +172,101 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------- BN + ReLU + max-pool as one unit (ResNet stem)
+// Forward: y_pool = maxpool(relu(x*scale + shift)) straight from the conv output: the full-resolution activation is
+// never written.  idx = argmax position inside the window (first max wins), 255 when the pooled value is <= 0 (ReLU
+// dead: no gradient).  Backward: the gradient of the (virtual) activation at a pixel is gathered from the <= 4 pooled
+// windows that contain it — g = sum of dp over windows whose argmax is this pixel — inside the two BN-backward passes,
+// so neither the un-pooled gradient nor a ReLU mask ever exists in memory.
+struct PoolMap {
+  int H, W, P, Q, k, stride, pad;
+  FastDiv div_hw, div_w;
+};
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16_t* __restrict__ x,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift,
+                                                                  bf16_t* __restrict__ y, unsigned char* __restrict__ idx,
+                                                                  PoolMap pm, int N, int C, long long total) {
+  const int c8 = C >> 3;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int ch = (int)(t % c8);
+    long long r = t / c8;
+    const int q = (int)(r % pm.Q); r /= pm.Q;
+    const int p = (int)(r % pm.P);
+    const int n = (int)(r / pm.P);
+    float sc[8], sh[8], best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[ch * 8 + e]; sh[e] = shift[ch * 8 + e]; best[e] = -INFINITY; bi[e] = 255; }
+    const int h0 = p * pm.stride - pm.pad, w0 = q * pm.stride - pm.pad;
+    for (int i = 0; i < pm.k; ++i) {
+      const int h = h0 + i;
+      if ((unsigned)h >= (unsigned)pm.H) continue;
+      for (int j = 0; j < pm.k; ++j) {
+        const int w = w0 + j;
+        if ((unsigned)w >= (unsigned)pm.W) continue;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + (((size_t)n * pm.H + h) * pm.W + w) * C + (size_t)ch * 8);
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = f[e] * sc[e] + sh[e];
+          if (a > best[e] || a != a) { best[e] = a; bi[e] = i * pm.k + j; }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (!(best[e] > 0.f) && best[e] == best[e]) { best[e] = 0.f; bi[e] = 255; }     // ReLU (NaN passes through)
+    const size_t o = (((size_t)n * pm.P + p) * pm.Q + q) * C + (size_t)ch * 8;
+    *reinterpret_cast<u32x4*>(y + o) = pack8(best);
+    u32x2 pk;
+    pk[0] = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+    pk[1] = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+    *reinterpret_cast<u32x2*>(idx + o) = pk;
+  }
+}
+
+// gradient of the virtual relu(bn(x)) activation at (row = (n,h,w), 8-channel chunk) from the pooled gradient
+__device__ __forceinline__ void pooled_grad8(const bf16_t* __restrict__ dp, const unsigned char* __restrict__ idx,
+                                             const PoolMap& pm, int row, int chunk, int C, float g[8]) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = 0.f;
+  const int n = (int)fastdiv((unsigned)row, pm.div_hw);
+  const int rem = row - n * (int)pm.div_hw.d;
+  const int h = (int)fastdiv((unsigned)rem, pm.div_w);
+  const int w = rem - h * pm.W;
+  const int hp = h + pm.pad, wp = w + pm.pad;
+  int p_lo = (hp - pm.k + pm.stride) / pm.stride; if (hp - pm.k + 1 <= 0) p_lo = 0;
+  int q_lo = (wp - pm.k + pm.stride) / pm.stride; if (wp - pm.k + 1 <= 0) q_lo = 0;
+  const int p_hi = min(hp / pm.stride, pm.P - 1), q_hi = min(wp / pm.stride, pm.Q - 1);
+  for (int p = p_lo; p <= p_hi; ++p) {
+    const int i = hp - p * pm.stride;
+    for (int q = q_lo; q <= q_hi; ++q) {
+      const int j = wp - q * pm.stride;
+      const unsigned me = (unsigned)(i * pm.k + j);
+      const size_t o = (((size_t)n * pm.P + p) * pm.Q + q) * C + (size_t)chunk * 8;
+      const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(dp + o);
+      float gf[8];
+      unpack8(gv, gf);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const unsigned b = ((e < 4 ? pk[0] : pk[1]) >> ((e & 3) * 8)) & 0xffu;
+        if (b == me) g[e] += gf[e];
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- backward: reductions
-template <bool RELU>
+// POOL: dy / mask are the POOLED gradient and the argmax bytes of bn_relu_maxpool_fwd_kernel (see pooled_grad8)
+template <bool RELU, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ slab,
-                                                            RowMap rm) {
+                                                            RowMap rm, PoolMap pm = PoolMap()) {
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
@@ -192,15 +281,19 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     for (int q = 0; q < 8; ++q) { mu[q] = mean[chunk * 8 + q]; is[q] = invstd[chunk * 8 + q]; }
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
       const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
       const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
       float g[8], xf[8];
-      unpack8(gv, g);
       unpack8(xv, xf);
-      if (RELU) {
-        const unsigned m = mask[(size_t)row * rm.c8 + chunk];
+      if (POOL) {
+        pooled_grad8(dy, mask, pm, row, chunk, rm.C, g);
+      } else {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+        unpack8(gv, g);
+        if (RELU) {
+          const unsigned m = mask[(size_t)row * rm.c8 + chunk];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+          for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+        }
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * (xf[q] - mu[q]) * is[q]; }
@@ -242,12 +335,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
   coefC[c] = -sc * mg + sc * mgx * invstd[c] * mean[c];
 }
 
-template <bool RELU, bool DRES>
+template <bool RELU, bool DRES, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
                                                            bf16_t* __restrict__ dres, const float* __restrict__ coefA,
                                                            const float* __restrict__ coefB,
-                                                           const float* __restrict__ coefC, RowMap rm) {
+                                                           const float* __restrict__ coefC, RowMap rm,
+                                                           PoolMap pm = PoolMap()) {
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
   const int chunk = blockIdx.y * rm.cpb + col;
@@ -258,15 +352,19 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
     const int row = rm.M - 1 - r0;          // tail first: what the reduce pass read last is still cached
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-    const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
     const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
     float g[8], xf[8];
-    unpack8(gv, g);
     unpack8(xv, xf);
-    if (RELU) {
-      const unsigned m = mask[(size_t)row * rm.c8 + chunk];
+    if (POOL) {
+      pooled_grad8(dy, mask, pm, row, chunk, rm.C, g);
+    } else {
+      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+      unpack8(gv, g);
+      if (RELU) {
+        const unsigned m = mask[(size_t)row * rm.c8 + chunk];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+        for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+      }
     }
     if (DRES) *reinterpret_cast<u32x4*>(dres + off) = pack8(g);
     float o[8];
@@ -338,5 +436,45 @@ extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, 
     if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
     else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   }
+  return (int)hipGetLastError();
+}
+
+static PoolMap make_poolmap(int H, int W, int P, int Q, int k, int stride, int pad) {
+  PoolMap pm;
+  pm.H = H; pm.W = W; pm.P = P; pm.Q = Q; pm.k = k; pm.stride = stride; pm.pad = pad;
+  pm.div_hw = make_fastdiv((unsigned)(H * W));
+  pm.div_w = make_fastdiv((unsigned)W);
+  return pm;
+}
+
+// y_pool [N][P][Q][C], idx [N][P][Q][C] bytes  <-  maxpool_k/stride/pad(relu(x*scale + shift)),  x [N][H][W][C]
+extern "C" int ddl_bn_relu_maxpool_fwd(const void* x, const float* scale, const float* shift, void* y, void* idx, int N,
+                                       int H, int W, int C, int P, int Q, int k, int stride, int pad, void* stream) {
+  if (C % 8 != 0 || k * k > 254 || N <= 0) return -1;
+  const PoolMap pm = make_poolmap(H, W, P, Q, k, stride, pad);
+  const long long total = (long long)N * P * Q * (C / 8);
+  hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, scale, shift, (bf16_t*)y, (unsigned char*)idx, pm, N, C, total);
+  return (int)hipGetLastError();
+}
+
+// BN backward of the fused unit: dp / idx are the pooled gradient and argmax bytes, x the conv output [N][H][W][C].
+extern "C" int ddl_bn_relu_maxpool_bwd(const void* dp, const void* idx, const void* x, const float* gamma,
+                                       const float* mean, const float* invstd, void* dx, float* dgamma, float* dbeta,
+                                       float* slab, float* coef, int N, int H, int W, int C, int P, int Q, int k,
+                                       int stride, int pad, int accumulate, void* stream) {
+  const long long M = (long long)N * H * W;
+  if (C % 8 != 0 || M <= 0 || M >= (1ll << 31)) return -1;
+  hipStream_t st = (hipStream_t)stream;
+  const RowMap rm = make_rowmap((int)M, C);
+  const dim3 grid = rowmap_grid(rm);
+  const PoolMap pm = make_poolmap(H, W, P, Q, k, stride, pad);
+  const bf16_t* dpp = (const bf16_t*)dp; const unsigned char* ip = (const unsigned char*)idx; const bf16_t* xp = (const bf16_t*)x;
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), grid, dim3(256), 0, st, dpp, ip, xp, mean, invstd, slab, rm, pm);
+  float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
+                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), grid, dim3(256), 0, st, dpp, ip, xp, (bf16_t*)dx,
+                     (bf16_t*)nullptr, cA, cB, cC, rm, pm);
   return (int)hipGetLastError();
 }

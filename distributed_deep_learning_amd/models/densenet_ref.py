@@ -17,7 +17,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
-from ..nn.modules import conv_bn_act, to_device_input
+from ..nn.modules import conv_bn_act, conv_bn_relu_pool, to_device_input
 
 
 class DenseLayer(tnn.Module):
@@ -93,7 +93,7 @@ class DenseNetRef(tnn.Module):
 
     def _stem(self, x):
         x = to_device_input(x)
-        return self.pool0(conv_bn_act(self.conv0, self.norm0, x, relu=True))
+        return conv_bn_relu_pool(self.conv0, self.norm0, self.pool0, x)
 
     def stages(self):
         """Logical layers for the model-parallel partitioner (the reference's layer ids, ``model.py:155-184``)."""

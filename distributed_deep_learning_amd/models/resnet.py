@@ -15,7 +15,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
-from ..nn.modules import conv_bn_act, residual_block, to_device_input
+from ..nn.modules import conv_bn_act, conv_bn_relu_pool, residual_block, to_device_input
 
 
 def _conv3x3(cin, cout, stride=1):
@@ -107,8 +107,9 @@ class ResNet(tnn.Module):
     # The stages below are what the model-parallel / pipeline wrappers split on.
     def stem(self, x):
         x = to_device_input(x)
-        x = conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        return self.maxpool(x)
+        if self.cifar_stem:
+            return conv_bn_act(self.conv1, self.bn1, x, relu=True)
+        return conv_bn_relu_pool(self.conv1, self.bn1, self.maxpool, x)
 
     def head(self, x):
         return self.fc(self.avgpool(x))

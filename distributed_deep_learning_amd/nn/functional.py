@@ -91,6 +91,46 @@ class ConvBNAct(torch.autograd.Function):
         return (dx, dw, dgamma, dbeta, dres) + (None,) * 11
 
 
+class ConvBNReluPool(torch.autograd.Function):
+    """Stem unit conv -> BN(train) -> ReLU -> max-pool with the un-pooled activation (and its gradient) never written:
+    the pooling is folded into the BN apply pass forward and into both BN-backward passes (``csrc/bn.hip``)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, w_krsc, w_crsk, running_mean, running_var, momentum, eps, stride, pad,
+                cin_real, slabs, pool):
+        x = K.nhwc(_bf16(x))
+        y_conv, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True, slab=slabs[0] if slabs else None)
+        N, _, P, Q = y_conv.shape
+        vec = K.bn_finalize(stats, N * P * Q, gamma, beta, running_mean, running_var, momentum, eps)
+        rows = K.vec_rows(vec)
+        out, idx = K.bn_relu_maxpool_fwd(y_conv, rows[2], rows[3], *pool)
+        ctx.save_for_backward(x, y_conv, idx, vec, gamma, w_crsk)
+        ctx.geom = (stride, pad, w_krsc.shape[1], w_krsc.shape[2], cin_real, pool)
+        ctx.weight = weight
+        ctx.bn_params = (gamma, beta)
+        ctx.slab = slabs[1] if slabs else None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y_conv, idx, vec, gamma, w_crsk = ctx.saved_tensors
+        stride, pad, R, S, cin_real, pool = ctx.geom
+        dout = K.nhwc(_bf16(dout))
+        rows = K.vec_rows(vec)
+        arena, gout = _bn_grad_out(*ctx.bn_params)
+        dconv, dgamma, dbeta = K.bn_relu_maxpool_bwd(dout, idx, y_conv, gamma, rows[0], rows[1], *pool, slab=ctx.slab,
+                                                     grad_out=gout)
+        if arena is not None:
+            arena.notify_grad_ready(ctx.bn_params[0])
+            arena.notify_grad_ready(ctx.bn_params[1])
+            dgamma = dbeta = None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = K.conv2d_dgrad(dconv, w_crsk, tuple(x.shape[2:]), stride, pad)
+        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
+        return (dx, dw, dgamma, dbeta) + (None,) * 11
+
+
 class ResidualBlock(torch.autograd.Function):
     """A whole residual block (ResNet BasicBlock / Bottleneck) as ONE autograd node.
 

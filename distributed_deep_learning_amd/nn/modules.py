@@ -187,6 +187,24 @@ def conv_bn_act(conv: Conv2d, bn: BatchNorm2d, x, relu: bool = True, residual=No
     return bn(conv(x), residual=residual, relu=relu)
 
 
+def conv_bn_relu_pool(conv: Conv2d, bn: BatchNorm2d, pool, x):
+    """conv -> BN -> ReLU -> max-pool (the ResNet / DenseNet stem).  In training on the GPU this is ONE fused unit
+    whose full-resolution activation and gradient are never written (:class:`functional.ConvBNReluPool`)."""
+    k, s, p = getattr(pool, "kernel_size", None), getattr(pool, "stride", None), getattr(pool, "padding", None)
+    simple = (isinstance(pool, tnn.MaxPool2d) and all(isinstance(v, int) for v in (k, s, p)) and pool.dilation == 1
+              and not pool.ceil_mode and not pool.return_indices and 2 * p <= k and k * k < 255)
+    if (simple and x.is_cuda and torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine
+            and conv.bias is None and conv._native_ok() and conv.out_channels % 8 == 0):
+        if x.shape[1] != _pad8(conv.in_channels):
+            x = to_device_input(x)
+        krsc, crsk = conv.packed()
+        bn._count_batch()
+        return F.ConvBNReluPool.apply(x, conv.weight, bn.weight, bn.bias, krsc, crsk, bn.running_mean, bn.running_var,
+                                      bn._momentum(), bn.eps, conv.stride[0], conv.padding[0], conv.in_channels,
+                                      bn.slabs(x.device), (k, s, p))
+    return pool(conv_bn_act(conv, bn, x, relu=True))
+
+
 def residual_block(units, ds, x):
     """Run a residual block — ``units``: main-path (conv, bn) pairs, ``ds``: optional projection (conv, bn) — as one
     fused autograd node on the GPU (see :class:`functional.ResidualBlock`); layer-by-layer elsewhere."""

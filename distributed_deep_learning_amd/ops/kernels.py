@@ -221,6 +221,52 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
     return dx, dres, dgb[0], dgb[1]
 
 
+def bn_relu_maxpool_fwd(x, scale, shift, k, stride, pad):
+    """``maxpool(relu(x*scale + shift))`` straight from the conv output ``x``: returns ``(y_pool, idx)`` — the
+    full-resolution activation is never written.  ``idx`` (uint8, shape of ``y_pool``) feeds
+    :func:`bn_relu_maxpool_bwd`."""
+    lib = _lib.require()
+    _chk_act(x, "bn_relu_maxpool_fwd")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    P, Q = conv_out_size(H, k, stride, pad), conv_out_size(W, k, stride, pad)
+    if pad * 2 > k:
+        raise ValueError("bn_relu_maxpool_fwd: padding larger than half the window")
+    y = torch.empty((N, Cc, P, Q), dtype=BF16, device=x.device, memory_format=CL)
+    idx = torch.empty((N, P, Q, Cc), dtype=torch.uint8, device=x.device)
+    check(lib.ddl_bn_relu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(idx), N, H, W, Cc, P, Q, k, stride, pad,
+                                      stream_ptr()), "bn_relu_maxpool_fwd")
+    return y, idx
+
+
+def bn_relu_maxpool_bwd(dp, idx, x, gamma, mean, invstd, k, stride, pad, slab=None, grad_out=None):
+    """Backward of conv-output -> BN -> ReLU -> max-pool as one unit: ``dp`` is the gradient of the POOLED output.
+    Returns ``(dx, dgamma, dbeta)`` with ``dx`` the gradient of the conv output ``x``."""
+    lib = _lib.require()
+    _chk_act(dp, "bn_relu_maxpool_bwd")
+    dp, x = nhwc(dp), nhwc(x)
+    N, Cc, H, W = x.shape
+    _, _, P, Q = dp.shape
+    if idx.dtype != torch.uint8 or idx.numel() != dp.numel() or not idx.is_contiguous():
+        raise ValueError("bn_relu_maxpool_bwd: idx must be the uint8 argmax tensor of bn_relu_maxpool_fwd")
+    dx = torch.empty_like(x, memory_format=CL)
+    if grad_out is not None:
+        dg, db = grad_out
+        if not (dg.is_contiguous() and db.is_contiguous() and dg.numel() == Cc and db.numel() == Cc
+                and dg.dtype == torch.float32 and db.dtype == torch.float32):
+            raise ValueError("bn_relu_maxpool_bwd: grad_out must be two contiguous fp32 [C] tensors")
+    else:
+        both = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
+        dg, db = both[0], both[1]
+    if slab is None:
+        slab = new_slab(Cc, x.device)
+    coef = slab.data_ptr() + _lib.bn_slots() * 2 * Cc * 4
+    check(lib.ddl_bn_relu_maxpool_bwd(ptr(dp), ptr(idx), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
+                                      ptr(db), ptr(slab), coef, N, H, W, Cc, P, Q, k, stride, pad,
+                                      int(grad_out is not None), stream_ptr()), "bn_relu_maxpool_bwd")
+    return dx, dg, db
+
+
 # ----------------------------------------------------------------------------------------------- pooling
 def maxpool_fwd(x, k, stride, pad):
     lib = _lib.require()
