@@ -230,8 +230,23 @@ __global__ __launch_bounds__(256 * G) void conv_wgrad_kernel(const WgradParams p
 // [pixel][channel] layout, so no transform is needed: the transposing LDS read does the rest) into a 4-stage ring of
 // 32-pixel steps, THREE steps in flight, zero fill by out-of-range buffer offsets, one counted-vmcnt barrier per
 // step.  64 KiB of LDS per block at 128x128: two blocks per CU, 96 KiB in flight per CU.
-__device__ __forceinline__ void wg_lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
+// Issued from inline asm ON PURPOSE: hipcc models an LDS-DMA it can see as a pending LDS store and drains it with
+// `s_waitcnt vmcnt(0)` before the next transposing LDS read (ds_read_b64_tr_b16 carries no alias information), which
+// serialises the whole ring (seen in the .s: one vmcnt(0) per K-step, kernel 11 % SLOWER than register staging).
+// Hidden in asm, the only waits are the counted ones below.  M0 = LDS byte address of the 1 KiB destination.
+__device__ __forceinline__ void wg_lds_dma16(const u32x4 rsrc, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");   // M0 has no other user in this kernel
+}
+
+__device__ __forceinline__ u32x4 wg_make_rsrc(const void* base, unsigned long long bytes) {
+  const unsigned long long a = (unsigned long long)base;
+  u32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffffu);     // stride 0, no swizzle
+  r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);                    // num_records (bytes): range check
+  r[3] = 0x00020000u;
+  return r;
 }
 
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
@@ -271,8 +286,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
 
-  const __amdgpu_buffer_rsrc_t ysrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.dy_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t xsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+  const u32x4 ysrc = wg_make_rsrc(p.dy, p.dy_bytes);
+  const u32x4 xsrc = wg_make_rsrc(p.x, p.x_bytes);
+  const unsigned smem_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
 
   // ---- staging geometry.  Instruction j of wave w fills tile rows (j*4 + w)*RW .. +RW-1; lane -> (row, physical
   //      chunk); the XOR swizzle of tr_off<> depends only on row bits that are fixed per thread (see tr_off), so the
@@ -292,32 +308,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   const unsigned ycol_off = (unsigned)(k0 + ych * 8);
 
   auto issue = [&](int stage, int mbase) {
-    char* const sb = smem + stage * STAGE;
+    const unsigned sb = smem_addr + (unsigned)(stage * STAGE);
 #pragma unroll
     for (int j = 0; j < YJ; ++j) {
       const int m = mbase + (j * 4 + wid) * YRW + yrow;
       const unsigned off = ((unsigned)m * (unsigned)p.K + ycol_off) * 2u;
-      wg_lds_dma16(ysrc, sb + (j * 4 + wid) * 1024, (ycol_ok && m < m_end) ? off : OOB);
+      wg_lds_dma16(ysrc, sb + (unsigned)((j * 4 + wid) * 1024), (ycol_ok && m < m_end) ? off : OOB);
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
       const int m = mbase + (j * 4 + wid) * XRW + xrow;
-      unsigned off = OOB;
-      if (xcol_ok && m < m_end) {
-        if (p.plain) {
-          off = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
-        } else {
-          const unsigned n = fastdiv((unsigned)m, p.div_pq);
-          const unsigned rem = (unsigned)m - n * p.div_pq.d;
-          const unsigned pp = fastdiv(rem, p.div_q);
-          const unsigned qq = rem - pp * p.div_q.d;
-          const int ih = (int)pp * p.stride - p.pad + r;
-          const int iw = (int)qq * p.stride - p.pad + xs;
-          if ((unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W)
-            off = ((unsigned)((int)n * p.H * p.W + ih * p.W + iw) * (unsigned)p.C + (unsigned)xc) * 2u;
-        }
+      unsigned off;
+      bool ok = xcol_ok && m < m_end;
+      if (p.plain) {                              // wave-uniform
+        off = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
+      } else {                                    // branch-free: every lane decodes, invalid lanes read out of range
+        const unsigned n = fastdiv((unsigned)m, p.div_pq);
+        const unsigned rem = (unsigned)m - n * p.div_pq.d;
+        const unsigned pp = fastdiv(rem, p.div_q);
+        const unsigned qq = rem - pp * p.div_q.d;
+        const int ih = (int)pp * p.stride - p.pad + r;
+        const int iw = (int)qq * p.stride - p.pad + xs;
+        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        off = ((unsigned)((int)n * p.H * p.W + ih * p.W + iw) * (unsigned)p.C + (unsigned)xc) * 2u;
       }
-      wg_lds_dma16(xsrc, sb + YBYTES + (j * 4 + wid) * 1024, off);
+      wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + (j * 4 + wid) * 1024), ok ? off : OOB);
     }
   };
 
@@ -424,8 +439,10 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   // One full round of resident blocks (2 per CU x 256 CUs), never more: a grid of 1.1 rounds runs as long as 2,
   // and every extra split adds a tile of fp32 atomic traffic (~1.3 TB/s chip-wide).  Splits are never shorter
   // than 256 pixels (4 K-steps).
-  // DDL_WGRAD_RING=1 selects the LDS-DMA ring variant (measured slower on ResNet-50: 5.74 vs 5.17 ms per step).
-  static const int use_ring = [] { const char* e = getenv("DDL_WGRAD_RING"); return e ? atoi(e) : 0; }();
+  // DDL_WGRAD_RING=0 falls back to the register-staged kernel (also used for operands beyond 4 GiB).  Measured on
+  // ResNet-50 (bench/conv_layers.py w): the ring is ~15 % faster at batch 512 once its DMA issue is hidden from
+  // hipcc's waitcnt insertion (see wg_lds_dma16).
+  static const int use_ring = [] { const char* e = getenv("DDL_WGRAD_RING"); return e ? atoi(e) : 1; }();
   static const int groups = [] { const char* e = getenv("DDL_WGRAD_GROUPS"); return e ? atoi(e) : 2; }();
   const bool ring = use_ring && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull;
   // Measured per layer (bench/conv_layers.py, B=256): pairing the groups pays where the atomic tail dominates, i.e. the
