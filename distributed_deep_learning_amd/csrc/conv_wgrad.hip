@@ -249,6 +249,9 @@ __device__ __forceinline__ u32x4 wg_make_rsrc(const void* base, unsigned long lo
   return r;
 }
 
+#ifndef WG_RING_STAGES
+#define WG_RING_STAGES 4
+#endif
 template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -256,13 +259,15 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
 template <int TK, int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams p) {
   constexpr int BKP = 32;                        // pixels per ring stage
-  constexpr int NS = 4;                          // ring stages (NS - 1 in flight)
+  constexpr int NS = WG_RING_STAGES;             // ring stages (NS - 1 in flight)
   constexpr int YROWB = TK * 2, XROWB = TN * 2;  // bytes per tile row
   constexpr int YRW = 1024 / YROWB, XRW = 1024 / XROWB;      // rows per LDS-DMA wave-instruction (4 or 8)
   constexpr int YJ = BKP / (4 * YRW), XJ = BKP / (4 * XRW);  // instructions per thread per stage (2 or 1)
@@ -450,7 +455,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   // 8-wave barriers (+3..+50 %), so they keep independent 4-wave blocks.
   const double flops = 2.0 * (double)p.M * (double)p.K * (double)p.C * (double)p.R * (double)p.S;
   const int G = (!ring && groups == 2 && p.plain && flops < 40e9) ? 2 : 1;
-  const int smem = ring ? 4 * 32 * (TK + TN) * 2 : G * 2 * 64 * (TK + TN) * 2;
+  const int smem = ring ? WG_RING_STAGES * 32 * (TK + TN) * 2 : G * 2 * 64 * (TK + TN) * 2;
   static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
   const int max_cu = 4 / G;                                                   // 16 waves per CU at most
   const int per_cu = (160 * 1024) / smem < max_cu ? (160 * 1024) / smem : max_cu;   // LDS- and register-limited residency
