@@ -224,8 +224,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
       }
       u32x4 vo = v;
-      if (p.addend != nullptr) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + opix * (size_t)p.OC + (size_t)ncol);
+      size_t apix = opix;
+      bool take = p.addend != nullptr;
+      if (take && p.addend_step > 1) {
+        const size_t fhw = (size_t)p.FOH * p.FOW;
+        const size_t n = opix / fhw, rem = opix - n * fhw;
+        const int h = (int)(rem / p.FOW), w = (int)(rem - (size_t)h * p.FOW);
+        take = (h % p.addend_step == 0) && (w % p.addend_step == 0);
+        apix = (n * p.AH + (size_t)(h / p.addend_step)) * p.AW + (size_t)(w / p.addend_step);
+      }
+      if (take) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + apix * (size_t)p.OC + (size_t)ncol);
         float f[8], a[8];
         unpack8(v, f);
         unpack8(av, a);
@@ -304,7 +313,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
 }
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
-                              const void* addend, const void* addend_mask, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              const void* addend, const void* addend_mask, int addend_step, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
@@ -315,6 +324,9 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   p.addend = (const bf16_t*)addend;
   p.addend_mask = (const unsigned char*)addend_mask;
   if (addend_mask != nullptr && addend == nullptr) return -7;
+  if (addend_step < 1 || (addend_step > 1 && addend_mask != nullptr)) return -8;
+  p.addend_step = addend != nullptr ? addend_step : 1;
+  p.AH = (OH + addend_step - 1) / addend_step; p.AW = (OW + addend_step - 1) / addend_step;
   if (addend != nullptr && stats != nullptr) return -5;      // statistics are taken before the addend
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;

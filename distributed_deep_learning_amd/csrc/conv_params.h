@@ -8,6 +8,8 @@ struct ConvParams {
   bf16_t* out;
   const float* bias;   // optional [OC]
   const bf16_t* addend; // optional, same shape as out: out = conv + addend (gradient accumulation fused in dgrad)
+  int addend_step, AH, AW;              // > 1: the addend is COMPACT [N][AH][AW][OC] and lands on pixels (h, w) % step == 0 only
+  FastDiv div_fhw, div_fw;               // full-output pixel -> (n, h, w) for that case
   const unsigned char* addend_mask; // optional 1-bit-per-element mask on the addend ([pixels][OC/8] bytes, BN-apply layout)
   float* stats;        // optional [DDL_BN_SLOTS][2][OC] partial sums, accumulated with float atomics
   int N, OH, OW, IH, IW, IC, OC, R, S, stride, pad;

@@ -263,8 +263,19 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
       }
       u32x4 vo = v;
-      if ((EPI & 4) && p.addend != nullptr) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + opix * (size_t)p.OC + (size_t)ncol);
+      size_t apix = opix;
+      bool take = (EPI & 4) && p.addend != nullptr;
+      if ((EPI & 4) && p.addend_step > 1) {       // compact addend of a strided 1x1 shortcut: only every step-th pixel
+        const unsigned n = fastdiv((unsigned)opix, p.div_fhw);
+        const unsigned rem = (unsigned)opix - n * p.div_fhw.d;
+        const unsigned h = fastdiv(rem, p.div_fw);
+        const unsigned w = rem - h * p.div_fw.d;
+        const unsigned hs = h / (unsigned)p.addend_step, ws = w / (unsigned)p.addend_step;
+        take = take && (hs * p.addend_step == h) && (ws * p.addend_step == w);
+        apix = ((size_t)n * p.AH + hs) * p.AW + ws;
+      }
+      if (take) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + apix * (size_t)p.OC + (size_t)ncol);
         float f[8], a[8];
         unpack8(v, f);
         unpack8(av, a);
@@ -361,6 +372,8 @@ bool ddl_conv_ring_supported(const ConvParams& p) {
 int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream) {
   p.div_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
   p.div_ow = make_fastdiv((unsigned)p.OW);
+  p.div_fhw = make_fastdiv((unsigned)(p.FOH * p.FOW));
+  p.div_fw = make_fastdiv((unsigned)p.FOW);
   const int bk = ring_bk(p);
   if (p.OC <= 64) return bk == 32 ? dispatch_ring<64, 32>(p, mode, stream) : dispatch_ring<64, 64>(p, mode, stream);
   return bk == 32 ? dispatch_ring<128, 32>(p, mode, stream) : dispatch_ring<128, 64>(p, mode, stream);

@@ -179,7 +179,8 @@ class ResidualBlock(torch.autograd.Function):
         metas = ctx.metas
         grads = {}
 
-        def back(idx, dy, need_dx, addend=None, addend_mask=None, relu_mask=None, want_dres=False):
+        def back(idx, dy, need_dx, addend=None, addend_mask=None, relu_mask=None, want_dres=False, addend_step=1,
+                 compact_dx=False):
             """BN(+ReLU) backward -> dgrad (+ addend) -> wgrad of unit ``idx``.  ``relu_mask`` overrides the unit's
             own activation: the unit then sees ``dy * mask`` (used to push the block-output ReLU into the shortcut)."""
             inp, y_conv, mask, vec, crsk = saved[5 * idx:5 * idx + 5]
@@ -190,9 +191,13 @@ class ResidualBlock(torch.autograd.Function):
             dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
                                                  relu, want_dres, slab)
             dx = None
-            if need_dx:
+            if need_dx and compact_dx:
+                # strided 1x1 conv: its input gradient is non-zero only on the stride grid -> compute just that grid
+                # (a plain stride-1 dgrad over the output pixels); the consumer adds it with ``addend_step``
+                dx = K.conv2d_dgrad(dconv, crsk, tuple(dconv.shape[2:]), 1, 0)
+            elif need_dx:
                 dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend,
-                                    addend_mask=addend_mask)
+                                    addend_mask=addend_mask, addend_step=addend_step)
             R, S = conv.kernel_size
             dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
             grads[idx] = (dw, dgamma, dbeta)
@@ -211,8 +216,14 @@ class ResidualBlock(torch.autograd.Function):
             for idx in range(last - 1, first_main, -1):
                 d, _ = back(idx, d, True)
             if ctx.has_ds:
-                dshort, _ = back(0, dout, need_x, relu_mask=out_mask)
-                dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None)
+                dsc = metas[0][0]
+                step = dsc.stride[0]
+                fconv = metas[first_main][0]
+                compact = (step > 1 and dsc.kernel_size == (1, 1) and dsc.padding[0] == 0
+                           and fconv.stride[0] == 1)          # first main conv writes every input pixel in one launch
+                dshort, _ = back(0, dout, need_x, relu_mask=out_mask, compact_dx=compact)
+                dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None,
+                             addend_step=step if compact else 1)
             else:
                 dx, _ = back(first_main, d, need_x, addend=dout if need_x else None,
                              addend_mask=out_mask if need_x else None)

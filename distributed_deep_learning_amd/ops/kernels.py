@@ -80,18 +80,20 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
         raise TypeError("conv2d_fwd: bias must be fp32 [K]")
-    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, N, P, Q, H, W, Cc, K,
+    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, 1, N, P, Q, H, W, Cc, K,
                              R, S,
                              stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
     return y, stats
 
 
-def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None):
+def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None, addend_step=1):
     """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC).
     ``addend`` (bf16, shape of dx) is added in the epilogue: gradient accumulation of a second path for free.
     ``addend_mask`` (uint8 ``[N*H*W, C/8]``, the ReLU bit mask :func:`bn_apply` writes) zeroes the addend where its
     bit is clear: ``dx = dgrad + addend * mask`` — the residual-branch gradient ``dy * relu'(y)`` without ever
-    materialising it."""
+    materialising it.  ``addend_step`` s > 1: the addend is COMPACT ``[N, C, ceil(H/s), ceil(W/s)]`` and is added at
+    pixels ``(h, w)`` with ``h % s == w % s == 0`` only — the input gradient of a strided 1x1 projection shortcut,
+    which is zero everywhere else, without the zero-filled full-size tensor."""
     lib = _lib.require()
     _chk_act(dy, "conv2d_dgrad")
     dy = nhwc(dy)
@@ -106,8 +108,11 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
     if addend is not None:
         _chk_act(addend, "conv2d_dgrad(addend)")
         addend = nhwc(addend)
-        if addend.shape != dx.shape:
+        want = dx.shape if addend_step == 1 else (N, Cc, -(-H // addend_step), -(-W // addend_step))
+        if tuple(addend.shape) != tuple(want):
             raise ValueError("conv2d_dgrad: addend shape mismatch")
+        if addend_step > 1 and addend_mask is not None:
+            raise ValueError("conv2d_dgrad: a compact addend cannot be masked")
         if stride > 1 and (R < stride or S < stride):
             raise ValueError("conv2d_dgrad: addend not supported when stride exceeds the filter size")
     if addend_mask is not None:
@@ -115,7 +120,8 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
             raise ValueError("conv2d_dgrad: addend_mask needs an addend")
         if addend_mask.dtype != torch.uint8 or addend_mask.numel() != N * H * W * Cc // 8 or not addend_mask.is_contiguous():
             raise ValueError("conv2d_dgrad: addend_mask must be the contiguous uint8 [N*H*W, C/8] mask of bn_apply")
-    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, ptr(addend), ptr(addend_mask), N, H, W, P, Q,
+    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, ptr(addend), ptr(addend_mask), int(addend_step), N, H, W,
+                             P, Q,
                              K, Cc, R, S, stride, pad, 0, stream_ptr()), "conv2d_dgrad")
     return dx
 

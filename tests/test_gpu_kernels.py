@@ -102,6 +102,22 @@ def test_conv_dgrad_addend_epilogue(case, masked, monkeypatch):
     _close(dx, ref, what="dgrad + addend")
 
 
+def test_conv_dgrad_compact_strided_addend():
+    """addend_step=2: a compact [N,C,ceil(H/2),ceil(W/2)] addend lands on the even pixels only (projection shortcut)."""
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    for (N, C, H, W, Kc) in [(2, 256, 14, 14, 64), (3, 64, 9, 11, 128)]:
+        w = (torch.randn((Kc, C, 1, 1), generator=torch.Generator().manual_seed(2)) / C ** 0.5)
+        w = w.to(_dev()).contiguous(memory_format=CL)
+        w_krsc, w_crsk = K.filter_repack(w)
+        dy = _rand_act((N, Kc, H, W), 3)
+        comp = _rand_act((N, C, (H + 1) // 2, (W + 1) // 2), 4)
+        dx = K.conv2d_dgrad(dy, w_crsk, (H, W), 1, 0, addend=comp, addend_step=2)
+        ref = torch.nn.grad.conv2d_input((N, C, H, W), w_krsc.permute(0, 3, 1, 2).float(), dy.float(), 1, 0)
+        ref[:, :, ::2, ::2] += comp.float()
+        _close(dx, ref, what="dgrad + compact addend")
+
+
 def test_conv_bias_relu_epilogue():
     from distributed_deep_learning_amd.ops import kernels as K
 
