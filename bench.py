@@ -19,9 +19,9 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+# RCCL's intra-node transport needs dmabuf IPC on this host driver; must be in the environment before HIP starts.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-# Same-box comparator measured with bench/stock_resnet.py (stock PyTorch-ROCm: MIOpen + ATen BN, bf16 autocast,
-# channels_last, cudnn.benchmark) at per-GPU batch 256 on one MI355X; see BASELINE.md / profiles/.
 # stock PyTorch-ROCm ResNet-50 (bench/stock_models.py) on the same MI355X, img/s per GPU, keyed by per-GPU batch
 STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6793.5}
 
