@@ -295,3 +295,20 @@ extern "C" int ddl_nchw_to_nhwc_pad(const float* in, void* out, int N, int C, in
                      (bf16_t*)out, N, C, HW, Cp, total);
   return (int)hipGetLastError();
 }
+
+// One wave that stays resident for ~`ticks` wall-clock ticks (100 MHz), bounded by an iteration cap as well.  Used by
+// ops/streams.py to find out whether two HIP streams really run concurrently (= sit on different hardware queues).
+__global__ __launch_bounds__(64) void spin_kernel(long long ticks, int max_iter, int* __restrict__ sink) {
+  const long long t0 = wall_clock64();
+  int it = 0;
+  while (it < max_iter && wall_clock64() - t0 < ticks) {
+    ++it;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (sink != nullptr && it < 0) *sink = it;       // never true: keeps the loop observable
+}
+extern "C" int ddl_spin(long long microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 100000) return -1;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100, 1 << 22, (int*)nullptr);
+  return (int)hipGetLastError();
+}

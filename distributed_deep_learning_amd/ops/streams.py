@@ -40,15 +40,43 @@ def set_enabled(flag: bool) -> None:
     _ENABLED = bool(flag)
 
 
+def _overlaps(main: torch.cuda.Stream, cand: torch.cuda.Stream, us: int = 150) -> bool:
+    """True when a kernel on ``cand`` runs CONCURRENTLY with one on ``main``: two single-wave kernels that each stay
+    resident for ``us`` microseconds finish in ~1x that time on different hardware queues and in ~2x on a shared one."""
+    from . import _lib
+    lib = _lib.require()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    cand.wait_stream(main)
+    a.record(main)
+    lib.ddl_spin(us, main.cuda_stream)
+    lib.ddl_spin(us, cand.cuda_stream)
+    main.wait_stream(cand)
+    b.record(main)
+    b.synchronize()
+    return a.elapsed_time(b) * 1e3 < 1.6 * us
+
+
 def _stream(index: int) -> torch.cuda.Stream:
     s = _side.get(index)
     if s is None:
-        # A stream of a DIFFERENT priority class gets a hardware queue of its own.  Normal-priority streams are dealt
-        # round-robin onto GPU_MAX_HW_QUEUES (4) queues, and once RCCL has created its streams the side stream can
-        # land on the main stream's queue, where it overlaps nothing (measured: rocprof queue ids, kernel-time sum ==
-        # busy time).  DDL_WGRAD_STREAM_PRIORITY: -1 high (default), 0 normal.
-        prio = int(os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "-1"))
-        s = torch.cuda.Stream(device=index, priority=prio)
+        # HIP deals streams round-robin onto GPU_MAX_HW_QUEUES (4) hardware queues; once other libraries (RCCL, MIOpen)
+        # have created theirs, a new stream can land on the MAIN stream's queue, where it overlaps nothing (seen in
+        # rocprof: same queue id, kernel-time sum == busy time, -2 ms per step).  So the candidates are MEASURED and the
+        # first one that really runs beside the current stream is kept.  All at normal priority: a high-priority side
+        # stream gets a queue of its own by construction, but deadlocked (GPU-side, cross-queue barrier never
+        # released) in a process that had run MIOpen's RNN before — DDL_WGRAD_STREAM_PRIORITY=-1 re-enables that.
+        prio = int(os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "0"))
+        main = torch.cuda.current_stream(index)
+        cands = []
+        for _ in range(1 if prio != 0 else 5):
+            c = torch.cuda.Stream(device=index, priority=prio)
+            cands.append(c)
+            try:
+                if prio != 0 or torch.cuda.is_current_stream_capturing() or _overlaps(main, c):
+                    break
+            except Exception:                       # noqa: BLE001 - calibration is best effort
+                break
+        s = cands[-1]
         _side[index] = s
     return s
 

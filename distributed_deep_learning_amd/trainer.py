@@ -90,9 +90,14 @@ class Trainer:
         if not torch.cuda.is_available():
             raise RuntimeError("device 'gpu' requested but no GPU is visible")
         if cfg.mode in ("model", "pipeline"):
-            base = info.local_rank * cfg.stages
-            if base + cfg.stages > torch.cuda.device_count():
-                raise RuntimeError(f"{cfg.mode} mode needs {cfg.stages} GPUs per rank")
+            base, count = info.local_rank * cfg.stages, torch.cuda.device_count()
+            if base + cfg.stages > count:
+                # fewer GPUs than stages: stages share devices round-robin (the reference's LSTM self-test runs its four
+                # "devices" on one CPU the same way, LSTM/model.py:180-192) - exercises the staging code on a 1-GPU box
+                if info.rank == 0:
+                    print(f"[trainer] {cfg.mode} mode: {cfg.stages} stages on {count} visible GPU(s), sharing devices",
+                          flush=True)
+                return [torch.device(f"cuda:{(base + i) % count}") for i in range(cfg.stages)]
             return [torch.device(f"cuda:{base + i}") for i in range(cfg.stages)]
         return [torch.device(f"cuda:{info.local_rank}")]
 

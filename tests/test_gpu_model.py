@@ -255,3 +255,16 @@ def test_trainer_with_hip_graph_flag():
     assert getattr(t, "_graphed", None) is not None and t._graphed.replays > 0
     assert hist[1]["train_loss"] < hist[0]["train_loss"]
 
+
+
+@pytest.mark.parametrize("model,mode", [("mlp", "sequential"), ("lstm", "sequential"), ("cnn", "pipeline"), ("mlp", "model")])
+def test_trainer_gpu_reference_workloads(model, mode):
+    """The reference's three workloads and its model / pipeline modes through the Trainer on the GPU (stages may share
+    the one device, like the reference's all-CPU 4-"device" LSTM self-test, LSTM/model.py:180-192)."""
+    from distributed_deep_learning_amd.config import Config
+    from distributed_deep_learning_amd.trainer import Trainer
+    cfg = Config(model=model, device="gpu", mode=mode, epochs=2, batch=32, samples=256, stages=2, pipeline=8)
+    t = Trainer(cfg).setup()
+    hist = t.fit()
+    assert len(hist) == 3 and all(torch.isfinite(torch.tensor(h.get("train_loss", 0.0))) for h in hist[:2])
+    assert "test_acc" in hist[-1]
