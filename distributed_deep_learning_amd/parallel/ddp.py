@@ -36,9 +36,13 @@ from .arena import ParamArena
 class DistributedDataParallel(tnn.Module):
     def __init__(self, module: tnn.Module, bucket_mb: float = 32.0, mode: str = "allreduce",
                  arena: Optional[ParamArena] = None, process_group=None, broadcast_buffers: bool = True,
-                 first_bucket_mb: Optional[float] = None, force_collectives: bool = False):
+                 first_bucket_mb: Optional[float] = None, force_collectives: bool = False,
+                 grad_dtype: Optional[torch.dtype] = None):
         """``force_collectives``: issue the (identity) collectives even with a world size of 1 — lets a one-GPU box
-        drive the real RCCL path (async works, comm-stream ordering, reduce-scatter / all-gather shapes)."""
+        drive the real RCCL path (async works, comm-stream ordering, reduce-scatter / all-gather shapes).
+        ``grad_dtype=torch.bfloat16``: gradients travel in bf16 (each bucket is packed into a persistent bf16 buffer,
+        reduced, unpacked into the fp32 arena) — half the xGMI bytes for bandwidth-bound models such as VGG-16
+        (553 MB of fp32 gradients per step); the default reduces the fp32 arena in place, with no copies."""
         super().__init__()
         if mode not in ("allreduce", "ps"):
             raise ValueError("mode must be 'allreduce' or 'ps'")
@@ -57,6 +61,10 @@ class DistributedDataParallel(tnn.Module):
             raise ValueError("PS mode needs an arena built with shard_multiple = world size")
         self.arena = arena
         self.backend = td.get_backend(self.pg) if self.dist else "none"
+        if grad_dtype not in (None, torch.float32, torch.bfloat16):
+            raise ValueError("grad_dtype must be None / torch.float32 (in place) or torch.bfloat16")
+        self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None
+        self._comm_bufs: dict = {}
         self.broadcast_buffers = broadcast_buffers
         self._handles: List = []
         self._pending = [0] * len(arena.buckets)
@@ -121,23 +129,43 @@ class DistributedDataParallel(tnn.Module):
         with streams.comm_context(g):       # ordered behind the side-stream wgrads that wrote into this bucket
             self._launch_collective(b, g)
 
+    def _comm_buf(self, key, numel: int) -> torch.Tensor:
+        buf = self._comm_bufs.get(key)
+        if buf is None:
+            buf = torch.empty(numel, dtype=self.grad_dtype, device=self.arena.device)
+            self._comm_bufs[key] = buf
+        return buf
+
     def _launch_collective(self, b: int, g: torch.Tensor) -> None:
+        """Enqueue the bucket's collective; ``_handles`` gets ``(work, finish)`` where ``finish()`` (run after the wait,
+        on the current stream) unpacks a compressed buffer and / or applies the 1/world scale gloo cannot fuse."""
+        inv = 1.0 / self.world
+        nccl = self.backend == "nccl"
+        src = g
+        if self.grad_dtype is not None:
+            src = self._comm_buf(("bucket", b), g.numel())
+            src.copy_(g)                                             # pack: fp32 arena -> bf16 wire format
         if self.mode == "allreduce":
-            if self.backend == "nccl":
-                h = td.all_reduce(g, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
-                self._handles.append((h, None))
-            else:
-                h = td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._handles.append((h, g))
+            h = td.all_reduce(src, op=td.ReduceOp.AVG if nccl else td.ReduceOp.SUM, group=self.pg, async_op=True)
+            dst, part = g, src
         else:
             lo, hi = self.arena.shard_range(b, self.rank, self.world)
-            own = self.arena.grad[lo:hi]
-            if self.backend == "nccl":
-                h = td.reduce_scatter_tensor(own, g, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
-                self._handles.append((h, None))
+            dst = self.arena.grad[lo:hi]
+            off = lo - self.arena.buckets[b].lo
+            if nccl:
+                part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
+                h = td.reduce_scatter_tensor(part, src, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
             else:   # gloo has no reduce-scatter: same semantics via all-reduce, only the owned shard is used
-                h = td.all_reduce(g, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
-                self._handles.append((h, own))
+                h = td.all_reduce(src, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
+                part = src[off:off + (hi - lo)]
+
+        def finish(dst=dst, part=part, scale=not nccl):
+            if part.data_ptr() != dst.data_ptr() or part.dtype != dst.dtype:
+                dst.copy_(part)                                      # unpack (and / or pick the owned shard)
+            if scale:
+                dst.mul_(inv)
+
+        self._handles.append((h, finish))
 
     # ------------------------------------------------------------------ step boundary
     def finish_grad_sync(self) -> None:
@@ -151,11 +179,9 @@ class DistributedDataParallel(tnn.Module):
         for b in range(len(self.arena.buckets)):
             self._pending[b] = 0
         self._drain()
-        inv = 1.0 / self.world
-        for h, scale_view in self._handles:
+        for h, finish in self._handles:
             h.wait()
-            if scale_view is not None:
-                scale_view.mul_(inv)
+            finish()
         self._handles = []
         self._armed = False
 

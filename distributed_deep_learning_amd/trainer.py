@@ -129,7 +129,8 @@ class Trainer:
                 self.ddps.append(None)
                 continue
             if info.world > 1:
-                d = DistributedDataParallel(g, bucket_mb=cfg.bucket_mb, mode=cfg.sync)
+                d = DistributedDataParallel(g, bucket_mb=cfg.bucket_mb, mode=cfg.sync,
+                                            grad_dtype=torch.bfloat16 if cfg.grad_dtype == "bf16" else None)
                 if isinstance(model, StagedModel):
                     model.stages[gi] = d
                 else:
