@@ -301,6 +301,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   static const int use_ring = [] { const char* e = getenv("DDL_CONV_RING"); return e ? atoi(e) : 1; }();
   p.mode_hint = MODE;
   p.trace = g_conv_trace;
+  if (use_ring && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
   p.tiles_m = (p.M + 127) / 128;
   static const int force64 = [] { const char* e = getenv("DDL_CONV_BN64"); return e ? atoi(e) : 0; }();

@@ -19,6 +19,7 @@
 #include "common.h"
 #include "host_util.h"
 #include "conv_params.h"
+#include "conv_epilogue.h"
 #include <cstdlib>
 
 namespace {
@@ -208,114 +209,7 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   __syncthreads();     // all fragment reads done (nothing is in flight any more): the ring becomes epilogue space
   if (tracing) p.trace[blockIdx.x * 4 + 2] = wall_clock64();
 
-  // ---- epilogue: acc -> (bias, relu) -> bf16 tile in LDS -> full-line global stores (+ addend, + BN partial sums) ----
-  constexpr int OPITCH = (BN + 8) * 2;
-  char* const Os = smem;
-#pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int ch = wn * WN + i * 16 + (lane >> 4) * 4;
-    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-    if ((EPI & 1) && p.bias != nullptr) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) bv[q] = (n0 + ch + q < p.OC) ? p.bias[n0 + ch + q] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      const int px = wm * WM + j * 16 + (lane & 15);
-      float v[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] = acc[i][j][q];
-      if (EPI & 1) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bv[q];
-        if (p.relu) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], 0.f);
-        }
-      }
-      u32x2 pk;
-      pk[0] = pack_bf16x2(v[0], v[1]);
-      pk[1] = pack_bf16x2(v[2], v[3]);
-      *reinterpret_cast<u32x2*>(Os + px * OPITCH + ch * 2) = pk;
-    }
-  }
-  __syncthreads();
-
-  constexpr int CPR = BN / 8;       // 16-byte chunks per output row
-  constexpr int RPP = 512 / CPR;    // rows per pass
-  const int oc = tid % CPR, orow0 = tid / CPR;
-  const int ncol = n0 + oc * 8;
-  float s1[8], s2[8];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
-#pragma unroll
-  for (int pass = 0; pass < RBM / RPP; ++pass) {
-    const int row = orow0 + pass * RPP;
-    const int m = m0 + row;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * OPITCH + oc * 16);
-    if (m < p.M && ncol < p.OC) {
-      size_t opix = (size_t)m;
-      if (MODE == 1 && p.o_step != 1) {
-        const int n = (int)fastdiv((unsigned)m, p.div_ohw);
-        const int rem = m - n * (int)p.div_ohw.d;
-        const int oh = (int)fastdiv((unsigned)rem, p.div_ow);
-        const int ow = rem - oh * p.OW;
-        opix = ((size_t)n * p.FOH + (size_t)(oh * p.o_step + p.o_ph)) * p.FOW + (size_t)(ow * p.o_step + p.o_pw);
-      }
-      u32x4 vo = v;
-      size_t apix = opix;
-      bool take = (EPI & 4) && p.addend != nullptr;
-      if ((EPI & 4) && p.addend_step > 1) {       // compact addend of a strided 1x1 shortcut: only every step-th pixel
-        const unsigned n = fastdiv((unsigned)opix, p.div_fhw);
-        const unsigned rem = (unsigned)opix - n * p.div_fhw.d;
-        const unsigned h = fastdiv(rem, p.div_fw);
-        const unsigned w = rem - h * p.div_fw.d;
-        const unsigned hs = h / (unsigned)p.addend_step, ws = w / (unsigned)p.addend_step;
-        take = take && (hs * p.addend_step == h) && (ws * p.addend_step == w);
-        apix = ((size_t)n * p.AH + hs) * p.AW + ws;
-      }
-      if (take) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + apix * (size_t)p.OC + (size_t)ncol);
-        float f[8], a[8];
-        unpack8(v, f);
-        unpack8(av, a);
-        if (p.addend_mask != nullptr) {          // addend = (upstream gradient) x (ReLU mask of the block output)
-          const unsigned mk = p.addend_mask[opix * (size_t)(p.OC >> 3) + (size_t)(ncol >> 3)];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) a[q] = ((mk >> q) & 1u) ? a[q] : 0.f;
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) f[q] += a[q];
-        vo = pack8(f);
-      }
-      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
-      if (EPI & 2) {
-        float f[8];
-        unpack8(v, f);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
-      }
-    }
-  }
-  if (EPI & 2) {
-    static_assert(RBM * OPITCH <= RNS * STAGE && RPP * 2 * BN * 4 <= RNS * STAGE, "epilogue must fit in the ring");
-    __syncthreads();                                                // the output tile has been read out
-    float* const red = reinterpret_cast<float*>(smem);              // [RPP][2][BN], over the output tile
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
-      red[(orow0 * 2 + 1) * BN + oc * 8 + q] = s2[q];
-    }
-    __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid - which * BN;
-      float s = 0.f;
-#pragma unroll 4
-      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
-      if (n0 + col < p.OC)
-        atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
-    }
-  }
+  conv_epilogue_256<BN, MODE, EPI, RNS * STAGE>(p, smem, acc, tile_m, m0, n0, tid, lane, wm, wn);
   if (tracing) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // include the drain of this wave's output stores
     p.trace[blockIdx.x * 4 + 3] = wall_clock64();

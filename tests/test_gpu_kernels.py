@@ -39,6 +39,9 @@ CONV_CASES = [
     (1, 96, 8, 8, 128, 1, 1, 0),       # C not a multiple of 64
     (2, 32, 10, 10, 72, 5, 1, 2),      # 5x5, OC tail
     (4, 512, 7, 7, 512, 3, 1, 1),
+    (2, 64, 56, 56, 64, 3, 1, 1),      # LDS-resident patch kernel: 64-channel tile, wide rows
+    (3, 256, 14, 14, 256, 3, 1, 1),    # patch kernel: tiles span image boundaries, 8 channel slices
+    (1, 32, 20, 36, 96, 3, 1, 1),      # patch kernel: non-square, OC tail, single slice, M tail
 ]
 
 
