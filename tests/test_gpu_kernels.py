@@ -302,3 +302,39 @@ def test_bn_relu_maxpool_fused_unit(shape, pool):
     # bf16 ties in the pooled max can route a gradient to a different pixel of the window: compare in aggregate
     err = (dx.float() - xr.grad).abs()
     assert (err > 3e-2 + 3e-2 * xr.grad.abs()).float().mean().item() < 0.01, err.max().item()
+
+
+def test_conv_patch_kernel_opt_in_subprocess():
+    """The opt-in LDS-resident-patch 3x3 kernel (DDL_CONV_PATCH=1 is read once per process) against the default path."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+import torch.nn.functional as F
+from distributed_deep_learning_amd.ops import kernels as K
+CL = torch.channels_last
+dev = torch.device("cuda:0")
+for (N, C, H, W, Kc) in [(2, 64, 56, 56, 64), (3, 256, 14, 14, 256), (1, 32, 20, 36, 96)]:
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((N, C, H, W), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
+    w = (torch.randn((Kc, C, 3, 3), generator=g) / (C * 9) ** 0.5).to(dev).contiguous(memory_format=CL)
+    wk, wt = K.filter_repack(w)
+    wq = wk.permute(0, 3, 1, 2).float()
+    y, st = K.conv2d_fwd(x, wk, 1, 1, want_stats=True)
+    ref = F.conv2d(x.float(), wq, None, 1, 1)
+    assert (y.float() - ref).abs().max().item() < 2e-2 + 2e-2 * ref.abs().max().item()
+    s = st.sum(0)
+    assert torch.allclose(s[0], y.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-1)
+    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
+    add = torch.randn(x.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
+    dx = K.conv2d_dgrad(dy, wt, (H, W), 1, 1, addend=add)
+    dref = torch.nn.grad.conv2d_input((N, C, H, W), wq, dy.float(), 1, 1) + add.float()
+    assert (dx.float() - dref).abs().max().item() < 3e-2 + 2e-2 * dref.abs().max().item()
+print("PATCH_OK")
+''' % root
+    env = dict(os.environ, DDL_CONV_PATCH="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 0 and "PATCH_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
