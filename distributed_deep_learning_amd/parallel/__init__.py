@@ -4,7 +4,8 @@ from .ddp import DistributedDataParallel
 from .mp import (FnStage, StagedModel, partition_layers, reference_partition_cnn, reference_partition_lstm,
                  reference_partition_mlp, stage_modules)
 from .pipeline import PipelinedModel, schedule
+from .ps import ShardedDataParallel
 
 __all__ = ["CHUNK", "ParamArena", "plan_buckets", "DistributedDataParallel", "FnStage", "StagedModel",
            "partition_layers", "reference_partition_cnn", "reference_partition_lstm", "reference_partition_mlp",
-           "stage_modules", "PipelinedModel", "schedule"]
+           "stage_modules", "PipelinedModel", "schedule", "ShardedDataParallel"]
