@@ -179,7 +179,6 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
     }
     __builtin_amdgcn_s_barrier();           // everyone's part of tile t is in LDS; everyone is done with tile t-1
     asm volatile("" ::: "memory");
-    if (t + 2 < ksteps) issue(stage == 0 ? 2 : stage - 1);      // refill the stage tile t-1 just vacated
     const char* xb = smem + stage * STAGE;
     const char* wb = xb + XBYTES;
 #pragma unroll
@@ -198,6 +197,9 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
         const int sw = (BK == 64) ? ((row >> 1) & 7) : (3 * ((row >> 3) & 1));
         b[j] = *reinterpret_cast<const bf16x8*>(xb + row * RP + ((ch ^ sw) << 4));
       }
+      // refill the stage tile t-1 just vacated — AFTER this step's fragment reads are in flight, so the address
+      // arithmetic of the refill overlaps the LDS latency instead of delaying the first MFMA behind the barrier
+      if (ks == 0 && t + 2 < ksteps) issue(stage == 0 ? 2 : stage - 1);
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
