@@ -114,6 +114,8 @@ def fork(*operands: torch.Tensor):
 
 def join() -> None:
     """Make the current stream of every device with outstanding side-stream work wait for it."""
+    global _callback_queued
+    _callback_queued = False            # also recovers from a backward pass that died before its callback ran
     for index in list(_dirty):
         torch.cuda.current_stream(index).wait_stream(_side[index])
     _dirty.clear()
