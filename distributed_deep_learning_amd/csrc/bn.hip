@@ -11,6 +11,12 @@
 #include "common.h"
 #include "host_util.h"
 
+// Streaming 16-byte load: these passes touch every byte once, so the lines need not stay in L2 (measured on the
+// HBM probe, bench/probes/hbm_stream.hip: read-only streams 5.3-5.5 -> 6.0 TB/s with the nt hint).
+__device__ __forceinline__ u32x4 ld_stream(const bf16_t* p) {
+  return __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+}
+
 #define BN_SLOTS DDL_BN_SLOTS
 
 struct RowMap {
@@ -53,7 +59,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
   for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
   if (active) {
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
-      const u32x4 v = *reinterpret_cast<const u32x4*>(x + (size_t)row * rm.C + (size_t)chunk * 8);
+      const u32x4 v = ld_stream(x + (size_t)row * rm.C + (size_t)chunk * 8);
       float f[8];
       unpack8(v, f);
 #pragma unroll
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
     const int row = rm.M - 1 - r0;
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-    const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+    const u32x4 v = ld_stream(x + off);
     float f[8];
     unpack8(v, f);
 #pragma unroll
     for (int q = 0; q < 8; ++q) f[q] = f[q] * sc[q] + sh[q];
     if (RES) {
-      const u32x4 rv = *reinterpret_cast<const u32x4*>(res + off);
+      const u32x4 rv = ld_stream(res + off);
       float r[8];
       unpack8(rv, r);
 #pragma unroll
@@ -281,13 +287,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     for (int q = 0; q < 8; ++q) { mu[q] = mean[chunk * 8 + q]; is[q] = invstd[chunk * 8 + q]; }
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
       const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-      const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+      const u32x4 xv = ld_stream(x + off);
       float g[8], xf[8];
       unpack8(xv, xf);
       if (POOL) {
         pooled_grad8(dy, mask, pm, row, chunk, rm.C, g);
       } else {
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+        const u32x4 gv = ld_stream(dy + off);
         unpack8(gv, g);
         if (RELU) {
           const unsigned m = mask[(size_t)row * rm.c8 + chunk];
@@ -352,13 +358,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
     const int row = rm.M - 1 - r0;          // tail first: what the reduce pass read last is still cached
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-    const u32x4 xv = *reinterpret_cast<const u32x4*>(x + off);
+    const u32x4 xv = ld_stream(x + off);
     float g[8], xf[8];
     unpack8(xv, xf);
     if (POOL) {
       pooled_grad8(dy, mask, pm, row, chunk, rm.C, g);
     } else {
-      const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + off);
+      const u32x4 gv = ld_stream(dy + off);
       unpack8(gv, g);
       if (RELU) {
         const unsigned m = mask[(size_t)row * rm.c8 + chunk];
