@@ -79,7 +79,8 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
         apix = ((size_t)n * p.AH + hs) * p.AW + ws;
       }
       if (take) {
-        const u32x4 av = *reinterpret_cast<const u32x4*>(p.addend + apix * (size_t)p.OC + (size_t)ncol);
+        const u32x4 av = __builtin_nontemporal_load(                 // read exactly once: keep it out of L2
+            reinterpret_cast<const u32x4*>(p.addend + apix * (size_t)p.OC + (size_t)ncol));
         float f[8], a[8];
         unpack8(v, f);
         unpack8(av, a);

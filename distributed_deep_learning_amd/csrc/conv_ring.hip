@@ -31,6 +31,8 @@ constexpr int RNS = 3;        // ring stages
 __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_dst, unsigned voff) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds_dst, 16, voff, 0, 0, 0);
 }
+// (The non-temporal hint, aux bit 1, was tried for activation tiles that only one channel tile reads: 25-40 % SLOWER
+// on the 1x1 layers at 56x56 — the tile's lines come from the Infinity Cache, where the producer just left them.)
 
 // EPI bits: 1 = bias / ReLU epilogue, 2 = BN partial sums, 4 = addend (compile-time, so unused paths cost nothing)
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
