@@ -42,8 +42,8 @@ __global__ __launch_bounds__(256) void relu_fwd_kernel(const bf16_t* __restrict_
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                        bf16_t* __restrict__ dx, long long n8) {
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-    const u32x4 g = *reinterpret_cast<const u32x4*>(dy + i * 8);
-    const u32x4 v = *reinterpret_cast<const u32x4*>(y + i * 8);
+    const u32x4 g = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + i * 8));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + i * 8));
     float gf[8], yf[8];
     unpack8(g, gf);
     unpack8(v, yf);
@@ -87,11 +87,11 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const bf16_t* __restrict
   if (rg < rp && chunk < c8) {
     for (int row = blockIdx.x * rp + rg; row < M; row += gridDim.x * rp) {
       const size_t off = (size_t)row * C + (size_t)chunk * 8;
-      const u32x4 v = *reinterpret_cast<const u32x4*>(dy + off);
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(dy + off));
       float f[8];
       unpack8(v, f);
       if (GATE) {
-        const u32x4 yv = *reinterpret_cast<const u32x4*>(y + off);
+        const u32x4 yv = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(y + off));
         float yf[8];
         unpack8(yv, yf);
 #pragma unroll

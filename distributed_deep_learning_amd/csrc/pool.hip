@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const bf16_t* __restri
         const unsigned me = (unsigned)(i * g.k + j);
         const size_t o = (((size_t)n * g.P + p) * g.Q + q) * g.C + (size_t)ch * 8;
         const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
-        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + o);
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(dy + o);      // re-read by up to four pixels: default policy
         float gf[8];
         unpack8(gv, gf);
 #pragma unroll
