@@ -10,6 +10,7 @@
 // The ReLU mask travels as 1 bit per element (written by the forward apply), so the backward never re-reads y.
 #include "common.h"
 #include "host_util.h"
+#include <cstdlib>
 
 // Streaming 16-byte load: these passes touch every byte once, so the lines need not stay in L2 (measured on the
 // HBM probe, bench/probes/hbm_stream.hip: read-only streams 5.3-5.5 -> 6.0 TB/s with the nt hint).
@@ -35,6 +36,11 @@ static inline RowMap make_rowmap(int M, int C) {
   r.M = M;
   r.C = C;
   return r;
+}
+
+static inline int apply_grid_cap() {
+  static const int v = [] { const char* e = getenv("DDL_BN_APPLY_GRID"); return e ? atoi(e) : 1024; }();   // 512..8192 within 0.6 %
+  return v;
 }
 
 static inline dim3 rowmap_grid(const RowMap& r, int max_x = 2048) {
@@ -405,7 +411,7 @@ extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask,
                             const float* shift, int M, int C, int relu, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   const RowMap rm = make_rowmap(M, C);
-  const dim3 grid = rowmap_grid(rm);
+  const dim3 grid = rowmap_grid(rm, apply_grid_cap());
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* xp = (const bf16_t*)x; const bf16_t* rp = (const bf16_t*)res; bf16_t* yp = (bf16_t*)y;
   unsigned char* mp = (unsigned char*)mask;
@@ -435,12 +441,13 @@ extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, 
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
                      mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
   bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
+  const dim3 agrid = rowmap_grid(rm, apply_grid_cap());
   if (relu) {
-    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
-    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   } else {
-    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
-    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), grid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   }
   return (int)hipGetLastError();
 }
