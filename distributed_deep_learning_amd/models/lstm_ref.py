@@ -1,12 +1,15 @@
 """The reference's LSTM workload (``/root/reference/src/pytorch/LSTM/model.py:70-94``): Conv1d(10->64, k=1)+ReLU,
 MaxPool1d(1)+ReLU (an identity), ``hidden_layers`` stacked LSTMs over the 64 conv channels as the time axis
 (input size 32 -> hidden), final hidden state -> Linear(hidden->5).  Trained with L1 loss + Adam
-(``/root/reference/src/pytorch/LSTM/main.py:163-164``).  Parity model: the recurrent cell is a plain library op
-(MIOpen RNN / ATen), it is not on the north-star hot path.  84,293 parameters at the defaults."""
+(``/root/reference/src/pytorch/LSTM/main.py:163-164``).  On the GPU every LSTM layer is ONE launch of the fused
+recurrent kernel (``nn.LSTM`` -> ``csrc/lstm.hip``: weights in registers, all 64 steps inside the kernel); CPU tensors
+and unsupported widths take ``torch.nn.LSTM``.  84,293 parameters at the defaults."""
 from __future__ import annotations
 
 import torch
 import torch.nn as tnn
+
+from .. import nn as dnn
 
 
 class LSTMRef(tnn.Module):
@@ -16,7 +19,7 @@ class LSTMRef(tnn.Module):
             raise ValueError("Model requires at least one hidden layer")
         self.conv = tnn.Conv1d(history, 64, 1)
         self.lstms = tnn.ModuleList(
-            tnn.LSTM(features if i == 0 else hidden_params, hidden_params, batch_first=True) for i in range(hidden_layers))
+            dnn.LSTM(features if i == 0 else hidden_params, hidden_params, batch_first=True) for i in range(hidden_layers))
         self.fc = tnn.Linear(hidden_params, classes)
 
     def _front(self, x):
@@ -24,7 +27,7 @@ class LSTMRef(tnn.Module):
 
     def _lstm(self, i, x):
         out, (h, _c) = self.lstms[i](x)
-        return out if i + 1 < len(self.lstms) else h.squeeze(0)
+        return out if i + 1 < len(self.lstms) else h.squeeze(0).float()
 
     def stages(self):
         return [self._front] + [lambda x, i=i: self._lstm(i, x) for i in range(len(self.lstms))] + [self.fc]

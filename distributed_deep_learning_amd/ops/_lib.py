@@ -55,6 +55,9 @@ _SIGS = {
     "ddl_flat_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_flat_sgd": [_vp] * 9 + [_i, _i, _i, _vp],
     "ddl_flat_adam": [_vp] * 8 + [_i, _i, _i, _vp],
+    "ddl_lstm_supported": [_i, _i],
+    "ddl_lstm_fwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "ddl_lstm_bwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
 }
 
 

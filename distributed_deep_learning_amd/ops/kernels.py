@@ -439,6 +439,64 @@ def nchw_to_nhwc_pad(x: torch.Tensor, cp: int):
     return out
 
 
+# ----------------------------------------------------------------------------------------------- recurrent
+def lstm_supported(hidden: int, inputs: int) -> bool:
+    """Shapes with a compiled instance of the fused LSTM layer (constants mirrored from csrc/lstm.hip)."""
+    return hidden in (64, 128) and inputs in (32, 64, 128)
+
+
+def lstm_fwd(x, w_ih, w_hh, bias, h0=None, c0=None, save=True):
+    """One LSTM layer, all T steps in one launch.  ``x`` bf16 ``[B,T,I]`` (innermost contiguous), ``w_ih`` bf16
+    ``[4H,I]``, ``w_hh`` bf16 ``[4H,H]``, ``bias`` fp32 ``[4H]`` (= b_ih + b_hh), optional fp32/bf16 ``h0`` / ``c0``
+    ``[B,H]``.  Returns ``(hseq bf16 [B,T+1,H], cseq fp32 [B,T+1,H], gates bf16 [B,T,4,H] or None)``; row 0 of
+    ``hseq`` / ``cseq`` is the initial state, ``hseq[:, 1:]`` the output sequence."""
+    lib = _lib.require()
+    B, T, I = x.shape
+    H = w_hh.shape[1]
+    if x.dtype != BF16 or w_ih.dtype != BF16 or w_hh.dtype != BF16 or bias.dtype != torch.float32:
+        raise TypeError("lstm_fwd: x / w_ih / w_hh must be bf16 and bias fp32")
+    if x.stride(2) != 1:
+        x = x.contiguous()
+    if tuple(w_ih.shape) != (4 * H, I) or tuple(w_hh.shape) != (4 * H, H) or bias.numel() != 4 * H:
+        raise ValueError("lstm_fwd: weight shapes do not match")
+    if not lstm_supported(H, I):
+        raise ValueError(f"lstm_fwd: no compiled instance for hidden={H}, input={I}")
+    w_ih, w_hh, bias = w_ih.contiguous(), w_hh.contiguous(), bias.contiguous()
+    hseq = torch.empty((B, T + 1, H), dtype=BF16, device=x.device)
+    cseq = torch.empty((B, T + 1, H), dtype=torch.float32, device=x.device)
+    if h0 is None:
+        hseq[:, 0].zero_()
+    else:
+        hseq[:, 0].copy_(h0)
+    if c0 is None:
+        cseq[:, 0].zero_()
+    else:
+        cseq[:, 0].copy_(c0)
+    gates = torch.empty((B, T, 4, H), dtype=BF16, device=x.device) if save else None
+    check(lib.ddl_lstm_fwd(ptr(x), x.stride(0), x.stride(1), ptr(w_ih), ptr(w_hh), ptr(bias), ptr(hseq), ptr(cseq),
+                           ptr(gates), B, T, I, H, int(save), stream_ptr()), "lstm_fwd")
+    return hseq, cseq, gates
+
+
+def lstm_bwd(dout, gates, cseq, w_hh_t, want_state_grads=False):
+    """Reverse recurrence.  ``dout`` bf16 ``[B,T,H]`` (gradient of ``hseq[:, 1:]``), ``w_hh_t`` bf16 ``[H,4H]``.
+    Returns ``(dG bf16 [B,T,4H], dh0, dc0)`` — pre-activation gate gradients in PyTorch's i, f, g, o row order."""
+    lib = _lib.require()
+    B, T, four, H = gates.shape
+    if dout.dtype != BF16 or tuple(dout.shape) != (B, T, H):
+        raise ValueError("lstm_bwd: dout must be bf16 [B,T,H]")
+    if dout.stride(2) != 1 or dout.stride(0) % 4 or dout.stride(1) % 4:
+        dout = dout.contiguous()
+    if tuple(w_hh_t.shape) != (H, 4 * H) or w_hh_t.dtype != BF16 or not w_hh_t.is_contiguous():
+        raise ValueError("lstm_bwd: w_hh_t must be a contiguous bf16 [H,4H] tensor")
+    dG = torch.empty((B, T, 4 * H), dtype=BF16, device=dout.device)
+    dh0 = torch.empty((B, H), dtype=torch.float32, device=dout.device) if want_state_grads else None
+    dc0 = torch.empty((B, H), dtype=torch.float32, device=dout.device) if want_state_grads else None
+    check(lib.ddl_lstm_bwd(ptr(dout), dout.stride(0), dout.stride(1), ptr(gates), ptr(cseq), ptr(w_hh_t), ptr(dG),
+                           ptr(dh0), ptr(dc0), B, T, H, stream_ptr()), "lstm_bwd")
+    return dG, dh0, dc0
+
+
 # ----------------------------------------------------------------------------------------------- loss
 def softmax_xent(logits, target, want_grad=True):
     """Returns ``(out[2] = (mean loss, top-1 hits), dlogits or None)``; target is int64 ``[B]`` or fp32 ``[B,V]``."""

@@ -170,8 +170,9 @@ class ParamArena:
             K.filter_transpose_batched(self.shadow, self.shadow_t, descs, n, tiles)
 
     def notify_grad_ready(self, p) -> None:
-        """Called by kernels that accumulate straight into the arena gradient (bypassing autograd's
-        AccumulateGrad, so its hooks do not fire)."""
+        """Called by kernels that accumulate straight into the arena gradient and hand ``None`` to autograd.  (Autograd
+        still runs the parameter's post-accumulate hook for that undefined gradient, later; the reducer counts the
+        first signal per tensor and pass.)"""
         if self.on_grad_ready is not None:
             self.on_grad_ready(p._ddl_segment)                        # noqa: SLF001
 

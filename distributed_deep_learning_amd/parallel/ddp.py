@@ -68,6 +68,9 @@ class DistributedDataParallel(tnn.Module):
         self.broadcast_buffers = broadcast_buffers
         self._handles: List = []
         self._pending = [0] * len(arena.buckets)
+        self._seg_bucket = [sg.bucket for sg in arena.segments]
+        self._seen = [False] * len(arena.segments)
+        self.on_synced = None              # debug hook: called by step() once every bucket's collective has finished
         self._next_bucket = len(arena.buckets) - 1
         self._launched = [False] * len(arena.buckets)
         self._armed = False
@@ -75,11 +78,10 @@ class DistributedDataParallel(tnn.Module):
         self.sync_parameters()
         self._hooks = []
         if self.dist:
-            for p, s in zip(arena.params, arena.segments):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(s.bucket)))
+            for i, p in enumerate(arena.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
             # kernels that accumulate straight into the arena gradient report readiness through the arena
-            seg_bucket = [s.bucket for s in arena.segments]
-            arena.on_grad_ready = lambda seg: self._param_ready(seg_bucket[seg])
+            arena.on_grad_ready = lambda seg: self._segment_ready(seg)
 
     # ------------------------------------------------------------------ setup
     def sync_parameters(self) -> None:
@@ -100,20 +102,27 @@ class DistributedDataParallel(tnn.Module):
         for b, bk in enumerate(self.arena.buckets):
             self._pending[b] = len(bk.segments)
             self._launched[b] = False
+        for i in range(len(self._seen)):
+            self._seen[i] = False
         self._next_bucket = len(self.arena.buckets) - 1
         self._handles = []
         self._armed = True
 
     # ------------------------------------------------------------------ hooks
-    def _param_ready(self, bucket: int) -> None:
-        if not (self._armed and self.require_sync):
+    def _segment_ready(self, seg: int) -> None:
+        """First readiness signal of a segment in this backward pass counts, later ones are ignored: a kernel that
+        accumulated straight into the arena signals through ``arena.notify_grad_ready`` and returns ``None`` to
+        autograd, yet autograd still runs the parameter's post-accumulate hook for that undefined gradient — without
+        the ``_seen`` guard every such tensor would count twice and its bucket would be reduced half-filled."""
+        if not (self._armed and self.require_sync) or self._seen[seg]:
             return
-        self._pending[bucket] -= 1
+        self._seen[seg] = True
+        self._pending[self._seg_bucket[seg]] -= 1
         self._drain()
 
-    def _make_hook(self, bucket: int):
+    def _make_hook(self, seg: int):
         def hook(_param):
-            self._param_ready(bucket)
+            self._segment_ready(seg)
         return hook
 
     def _drain(self) -> None:
@@ -219,6 +228,8 @@ class DistributedDataParallel(tnn.Module):
     def step(self, optimizer) -> None:
         """finish grad sync -> (sharded) optimizer step -> (PS) parameter all-gather."""
         self.finish_grad_sync()
+        if self.on_synced is not None:
+            self.on_synced()
         optimizer.step(ranges=self.owned_ranges())
         if self.mode == "ps" and self.dist:
             # non-owned gradient ranges were not cleared by the sharded step

@@ -222,6 +222,72 @@ def test_grad_ledger_orders_buckets_and_catches_early_launch():
         assert o["div"] == 0.0
 
 
+# --------------------------------------------------------------------------------------------- direct arena writers
+class _DirectLinear(torch.autograd.Function):
+    """y = x @ w.T whose weight gradient is written straight into ``w.grad`` (an arena view) and reported through
+    ``arena.notify_grad_ready`` while autograd gets ``None`` — what the HIP wgrad / BN-backward kernels do."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        ctx.w = w
+        return x @ w.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        w = ctx.w
+        w.grad.add_(dy.t() @ x)
+        w._ddl_arena.notify_grad_ready(w)                # noqa: SLF001
+        return dy @ w.detach(), None
+
+
+class _DirectMLP(tnn.Module):
+    def __init__(self, seed):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.ws = tnn.ParameterList(tnn.Parameter(torch.randn(12, 12) * 0.3) for _ in range(6))
+        self.bs = tnn.ParameterList(tnn.Parameter(torch.zeros(12)) for _ in range(6))
+
+    def forward(self, x, direct=True):
+        for w, b in zip(self.ws, self.bs):
+            x = torch.tanh((_DirectLinear.apply(x, w) if direct else x @ w.t()) + b)
+        return x
+
+
+def _direct_worker(rank, world):
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena
+    from distributed_deep_learning_amd.utils import GradLedger
+    m = _DirectMLP(5)
+    arena = ParamArena(m.named_parameters(), bucket_bytes=8192, shard_multiple=world)     # a few tensors per bucket
+    ddp = DistributedDataParallel(m, arena=arena)
+    ledger = GradLedger(ddp)
+    x = torch.randn(8, 12, generator=torch.Generator().manual_seed(100 + rank))
+    ddp(x).pow(2).mean().backward()
+    over = max(ledger.signals.values())
+    ddp.finish_grad_sync()
+    synced = arena.grad.clone()
+    arena.zero_grad()
+    local = []
+    for r in range(world):                                # every rank's plain-autograd gradient, no communication
+        xr = torch.randn(8, 12, generator=torch.Generator().manual_seed(100 + r))
+        m(xr, direct=False).pow(2).mean().backward()
+        local.append(arena.grad.clone())
+        arena.zero_grad()
+    return {"synced": synced, "mean": sum(local) / world, "nb": len(arena.buckets), "over": over,
+            "order": ledger.launch_order()}
+
+
+def test_direct_arena_writers_are_counted_once():
+    """Tensors whose gradients bypass autograd's accumulation send TWO readiness signals (their own notify, then
+    autograd's hook for the undefined gradient); a bucket must still wait for all of its tensors."""
+    out = run_ranks(_direct_worker, 2)
+    for o in out:
+        assert o["nb"] > 2 and o["over"] == 2
+        assert o["order"] == list(range(o["nb"] - 1, -1, -1))
+        assert torch.allclose(o["synced"], o["mean"], atol=1e-6)
+
+
 # --------------------------------------------------------------------------------------------- bf16 wire format
 def _bf16_wire_worker(rank, world, mode):
     from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena

@@ -338,3 +338,51 @@ print("PATCH_OK")
     env = dict(os.environ, DDL_CONV_PATCH="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
     assert r.returncode == 0 and "PATCH_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
+
+
+# ----------------------------------------------------------------------------------------------- fused LSTM layer
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,I,H", [(40, 64, 32, 128), (16, 7, 64, 64), (33, 12, 128, 128), (5, 20, 32, 64)])
+def test_lstm_layer_matches_fp32_reference(B, T, I, H):
+    """Fused LSTM layer (csrc/lstm.hip) vs torch.nn.LSTM in fp32 on the CPU: outputs and all gradients."""
+    from distributed_deep_learning_amd import nn as dnn
+    torch.manual_seed(7)
+    ref = torch.nn.LSTM(I, H, batch_first=True)
+    ours = dnn.LSTM(I, H).cuda()
+    ours.load_state_dict(ref.state_dict())
+    x = torch.randn(B, T, I)
+    w = torch.randn(B, T, H) / T ** 0.5           # every time step contributes to the loss
+    xr = x.clone().requires_grad_(True)
+    out_r, (h_r, _) = ref(xr)
+    ((out_r * w).sum() + h_r.sum()).backward()
+    xg = x.cuda().requires_grad_(True)
+    assert ours.native_ok(xg)
+    out_g, (h_g, _) = ours(xg)
+    assert out_g.dtype == torch.bfloat16 and out_g.shape == (B, T, H)
+    ((out_g.float() * w.cuda()).sum() + h_g.float().sum()).backward()
+    torch.cuda.synchronize()
+
+    def rel(a, b):
+        return float((a.float().cpu() - b).norm() / (b.norm() + 1e-12))
+
+    assert rel(out_g, out_r) < 2e-2
+    assert rel(h_g[0], h_r[0]) < 2e-2
+    assert rel(xg.grad, xr.grad) < 3e-2
+    for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
+        assert rel(getattr(ours, name).grad, getattr(ref, name).grad) < 3e-2, name
+
+
+@pytest.mark.gpu
+def test_lstm_layer_no_grad_and_fallbacks():
+    from distributed_deep_learning_amd import nn as dnn
+    torch.manual_seed(3)
+    m = dnn.LSTM(32, 128).cuda()
+    x = torch.randn(24, 10, 32, device="cuda")
+    with torch.no_grad():
+        out, (h, c) = m(x)                          # inference: nothing saved
+    ref_out, (ref_h, _) = torch.nn.LSTM.forward(m, x)
+    assert float((out.float() - ref_out).abs().max()) < 3e-2
+    assert c is None and h.shape == (1, 24, 128)
+    odd = dnn.LSTM(20, 48).cuda()                   # no compiled instance -> stock path, fp32 out
+    o2, _ = odd(torch.randn(4, 6, 20, device="cuda"))
+    assert o2.dtype == torch.float32 and not odd.native_ok(torch.empty(4, 6, 20, device="cuda"))

@@ -142,6 +142,7 @@ def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
     from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
     from distributed_deep_learning_amd.optim import FusedSGD
     from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    from distributed_deep_learning_amd.utils import GradLedger
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", HSA_ENABLE_IPC_MODE_LEGACY="0")
     td.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
     try:
@@ -174,12 +175,23 @@ def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
             assert d.dist == force and len(d.arena.buckets) > 3
             o = FusedSGD(d.arena, lr=0.05, momentum=0.9)
             d.attach(o)
+            # The native kernels write gradients straight into the arena and report readiness themselves; at world 1
+            # a bucket reduced too early would go unnoticed (identity collective), so the ledger asserts the
+            # contract: every segment fires once, no bucket is launched with gradients outstanding.
+            ledger = GradLedger(d, snapshot=True) if force else None
             ls = []
             for _ in range(6):
                 loss = crit(d(x), y)
                 loss.backward()
-                d.step(o)
+                if force:
+                    # all buckets were launched from inside backward (overlap), last bucket first
+                    assert d._next_bucket == -1, d._next_bucket                   # noqa: SLF001
+                    assert ledger.launch_order() == list(range(len(d.arena.buckets) - 1, -1, -1))
+                    assert len(ledger.fired) == len(d.arena.segments) and set(d._pending) == {0}   # noqa: SLF001
+                d.step(o)                            # -> on_synced -> ledger.verify_complete (bucket snapshots)
                 ls.append(float(loss.detach()))
+            if force and wire is None:
+                assert ledger.verified == 6 * len(d.arena.buckets)
             return ls, d.arena.master.clone()
 
         base, wb = run("allreduce", False)
