@@ -1,4 +1,7 @@
-"""cProfile of the host side of the ResNet-50 training step (where does the enqueue time go?)."""
+"""cProfile of the host side of a training step (where does the enqueue time go?).
+
+    python bench/host_profile.py [batch] [resnet50|cnn|mlp|lenet5]
+"""
 import cProfile
 import pstats
 import sys
@@ -13,12 +16,15 @@ from distributed_deep_learning_amd.parallel import ParamArena  # noqa: E402
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-model = models.build("resnet50").to(dev)
+name = sys.argv[2] if len(sys.argv) > 2 else "resnet50"
+model = models.build(name).to(dev)
 arena = ParamArena(model.named_parameters())
 opt = FusedSGD(arena, lr=0.01, momentum=0.9)
 crit = SoftmaxCrossEntropyLoss()
-x = torch.randn(B, 3, 224, 224, device=dev)
-y = torch.randint(0, 1000, (B,), device=dev)
+shapes = {"resnet50": ((3, 224, 224), 1000), "cnn": ((3, 64, 64), 6), "mlp": ((48,), 5), "lenet5": ((1, 28, 28), 10)}
+shape, classes = shapes[name]
+x = torch.randn(B, *shape, device=dev)
+y = torch.randint(0, classes, (B,), device=dev)
 
 
 def step():

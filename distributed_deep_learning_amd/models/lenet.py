@@ -1,8 +1,9 @@
 """LeNet-5 on MNIST-shape input (north-star config 1: the CPU / gloo plumbing model).
 
 Classic layout: conv5x5(1->6, pad 2) - pool - conv5x5(6->16) - pool - fc120 - fc84 - fc10 (61,706 parameters).
-Channel counts 1/6 are below the GPU kernels' 8-channel granularity, so on a GPU the first conv falls back to
-ATen; the model exists for the plumbing config, which runs on CPU.
+Channel counts 1/6 are below the GPU kernels' 8-channel granularity: on a GPU the input is padded to 8 channels
+and conv1 pads its 6 output channels physically to 8 (``Conv2d(pad_out=True)``, the extra ones stay zero through
+ReLU and pooling), so both convolutions run on the MFMA kernels; on CPU (the gloo plumbing config) nothing changes.
 """
 from __future__ import annotations
 
@@ -14,7 +15,7 @@ from .. import nn as dnn
 class LeNet5(tnn.Module):
     def __init__(self, num_classes: int = 10, in_channels: int = 1):
         super().__init__()
-        self.conv1 = dnn.Conv2d(in_channels, 6, 5, 1, 2)
+        self.conv1 = dnn.Conv2d(in_channels, 6, 5, 1, 2, pad_out=True)
         self.pool1 = dnn.MaxPool2d(2, 2, 0)
         self.conv2 = dnn.Conv2d(6, 16, 5, 1, 0)
         self.pool2 = dnn.MaxPool2d(2, 2, 0)

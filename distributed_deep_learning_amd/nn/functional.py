@@ -21,11 +21,13 @@ def _bf16(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == BF16 else t.to(BF16)
 
 
-def _wgrad(weight, dy, x, R, S, stride, pad, cin_real):
+def _wgrad(weight, dy, x, R, S, stride, pad, cin_real, k_real=None):
     """Filter gradient.  When the parameter's ``.grad`` is a view of a flat arena, the split-K atomics of the wgrad
     kernel accumulate STRAIGHT into it (no temporary, no zero-fill, no autograd add) and ``None`` is returned to
     autograd; the arena then tells the data-parallel reducer that this tensor's gradient is ready."""
     arena = getattr(weight, "_ddl_arena", None)
+    if k_real is not None and k_real != dy.shape[1]:          # physically padded output channels (Conv2d pad_out)
+        return K.conv2d_wgrad(dy, x, R, S, stride, pad)[:k_real, :cin_real]
     if arena is not None and cin_real == x.shape[1] and arena.grad_is_arena_view(weight):
         with streams.fork(dy, x):          # side stream: overlaps the BN-backward / dgrad chain
             K.conv2d_wgrad(dy, x, R, S, stride, pad, out=weight.grad)
@@ -245,11 +247,12 @@ class ConvBiasAct(torch.autograd.Function):
     """y = act(conv(x, w) + b) with bias and ReLU fused into the conv epilogue (VGG / LeNet style blocks)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_krsc, w_crsk, stride, pad, relu, cin_real):
+    def forward(ctx, x, weight, bias, w_krsc, w_crsk, stride, pad, relu, cin_real, kernel_bias=None):
         x = K.nhwc(_bf16(x))
-        y, _ = K.conv2d_fwd(x, w_krsc, stride, pad, bias=bias, relu=relu)
+        y, _ = K.conv2d_fwd(x, w_krsc, stride, pad, bias=kernel_bias if kernel_bias is not None else bias, relu=relu)
         ctx.save_for_backward(x, y if relu else None, w_crsk)
         ctx.geom = (stride, pad, relu, bias is not None, w_krsc.shape[1], w_krsc.shape[2], cin_real)
+        ctx.k_real = weight.shape[0]
         ctx.weight = weight
         ctx.bias = bias
         return y
@@ -260,10 +263,12 @@ class ConvBiasAct(torch.autograd.Function):
         stride, pad, relu, has_bias, R, S, cin_real = ctx.geom
         dy = K.nhwc(_bf16(dy))
         db = None
+        k_real = ctx.k_real
+        padded = k_real != dy.shape[1]
         if relu and has_bias:                       # ReLU backward + bias gradient in one pass, straight into the arena
             bias = ctx.bias
             arena = getattr(bias, "_ddl_arena", None)
-            if arena is not None and arena.grad_is_arena_view(bias):
+            if not padded and arena is not None and arena.grad_is_arena_view(bias):
                 dy, _ = K.relu_bwd_bias_grad(dy, y, grad_out=bias.grad)
                 arena.notify_grad_ready(bias)
             else:
@@ -272,11 +277,13 @@ class ConvBiasAct(torch.autograd.Function):
             if relu:
                 dy = K.relu_bwd(dy, y)
             db = K.bias_grad(dy) if has_bias else None
+        if padded and db is not None:
+            db = db[:k_real]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real)
-        return (dx, dw, db) + (None,) * 6
+        dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real, k_real)
+        return (dx, dw, db) + (None,) * 7
 
 
 class BNAct(torch.autograd.Function):

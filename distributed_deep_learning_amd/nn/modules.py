@@ -43,10 +43,16 @@ def to_device_input(x: torch.Tensor) -> torch.Tensor:
 class Conv2d(tnn.Conv2d):
     """2-D convolution; GPU path = implicit-GEMM MFMA kernels (fwd / dgrad / wgrad)."""
 
-    def __init__(self, *args, **kwargs):
+    def __init__(self, *args, pad_out: bool = False, **kwargs):
+        """``pad_out=True``: on the GPU an output-channel count that is not a multiple of 8 (LeNet's 6) is padded
+        PHYSICALLY — the result has ``pad8(out_channels)`` channels, the extra ones exactly zero — instead of taking
+        the ATen fallback.  Meant for conv -> (ReLU / pool) -> conv chains: the next ``Conv2d`` accepts the padded
+        tensor as is.  Parameters keep their logical shapes; CPU tensors are unaffected."""
         super().__init__(*args, **kwargs)
         self.weight.data = self.weight.data.contiguous(memory_format=CL)
+        self.pad_out = bool(pad_out)
         self._pack = None
+        self._bias_pack = None
         self._warned = False
 
     # ---- geometry the kernels support
@@ -58,7 +64,7 @@ class Conv2d(tnn.Conv2d):
             and self.padding[0] == self.padding[1]
             and not isinstance(self.padding, str)
             and self.padding_mode == "zeros"
-            and self.out_channels % 8 == 0
+            and (self.out_channels % 8 == 0 or self.pad_out)
         )
 
     def packed(self):
@@ -73,9 +79,9 @@ class Conv2d(tnn.Conv2d):
             return self._pack[1], self._pack[2]
         with torch.no_grad():
             src = w.detach()
-            cin = src.shape[1]
-            if cin % 8 != 0:
-                src = TF.pad(src, (0, 0, 0, 0, 0, _pad8(cin) - cin)).contiguous(memory_format=CL)
+            k, cin = src.shape[0], src.shape[1]
+            if cin % 8 != 0 or k % 8 != 0:
+                src = TF.pad(src, (0, 0, 0, 0, 0, _pad8(cin) - cin, 0, _pad8(k) - k)).contiguous(memory_format=CL)
             elif not src.is_contiguous(memory_format=CL):
                 src = src.contiguous(memory_format=CL)
             krsc, crsk = K.filter_repack(src)
@@ -102,7 +108,17 @@ class Conv2d(tnn.Conv2d):
             x = to_device_input(x)
         krsc, crsk = self.packed()
         return F.ConvBiasAct.apply(x, self.weight, self.bias, krsc, crsk, self.stride[0], self.padding[0], relu,
-                                   self.in_channels)
+                                   self.in_channels, self._kernel_bias())
+
+    def _kernel_bias(self):
+        """fp32 bias as the kernel wants it: zero-padded to the physical channel count when ``pad_out`` is active."""
+        b = self.bias
+        if b is None or self.out_channels % 8 == 0:
+            return b
+        key = (b._version, _state.weights_epoch(), b.data_ptr())
+        if self._bias_pack is None or self._bias_pack[0] != key:
+            self._bias_pack = (key, TF.pad(b.detach().float(), (0, _pad8(self.out_channels) - self.out_channels)))
+        return self._bias_pack[1]
 
 
 class BatchNorm2d(tnn.BatchNorm2d):

@@ -42,6 +42,8 @@ CONV_CASES = [
     (2, 64, 56, 56, 64, 3, 1, 1),      # LDS-resident patch kernel: 64-channel tile, wide rows
     (3, 256, 14, 14, 256, 3, 1, 1),    # patch kernel: tiles span image boundaries, 8 channel slices
     (1, 32, 20, 36, 96, 3, 1, 1),      # patch kernel: non-square, OC tail, single slice, M tail
+    (4, 8, 28, 28, 8, 5, 1, 2),        # LeNet-5 conv1 (1 -> 6 channels, both padded to 8)
+    (4, 8, 14, 14, 16, 5, 1, 0),       # LeNet-5 conv2 (6 -> 16)
 ]
 
 
