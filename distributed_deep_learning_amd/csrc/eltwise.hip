@@ -204,6 +204,48 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_pad_kernel(const float* __re
   }
 }
 
+// Space-to-depth input for a 7x7 / stride 2 / pad 3 stem on 3-channel images (the ResNet / DenseNet stem):
+//   out[n][h2][w2][(p*2 + q)*3 + c] = in[n][c][2*(h2-1) + p - 1][2*(w2-1) + q - 1]      (0 outside the image)
+// with h2 in [0, H/2 + 3), channels 12..15 zero.  A 4x4 / stride 1 / pad 0 convolution over this tensor with the
+// filter regrouped the same way (tap r = 2a + p, r = 7 -> 0) IS the 7x7 stem: reduction length 256 instead of 392
+// (8-channel padded taps), no strided taps, and the padding is materialised so no bounds logic runs in the conv.
+__global__ __launch_bounds__(256) void nchw_to_s2d_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
+                                                           int N, int H, int W, int H2, int W2, long long total) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int w2 = (int)(t % W2);
+    const long long r = t / W2;
+    const int h2 = (int)(r % H2);
+    const int n = (int)(r / H2);
+    float f[16];
+#pragma unroll
+    for (int e = 12; e < 16; ++e) f[e] = 0.f;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      const int ih = 2 * (h2 - 1) + p - 1;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int iw = 2 * (w2 - 1) + q - 1;
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+          f[(p * 2 + q) * 3 + c] = ok ? in[(((size_t)n * 3 + c) * H + ih) * W + iw] : 0.f;
+      }
+    }
+    bf16_t* o = out + (size_t)t * 16;
+    *reinterpret_cast<u32x4*>(o) = pack8(f);
+    *reinterpret_cast<u32x4*>(o + 8) = pack8(f + 8);
+  }
+}
+
+extern "C" int ddl_nchw_to_s2d(const float* in, void* out, int N, int H, int W, void* stream) {
+  if (N <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return -1;
+  const int H2 = H / 2 + 3, W2 = W / 2 + 3;
+  const long long total = (long long)N * H2 * W2;
+  hipLaunchKernelGGL(nchw_to_s2d_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, in,
+                     (bf16_t*)out, N, H, W, H2, W2, total);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ddl_cast_f32_bf16(const float* in, void* out, long long n, void* stream) {
   if (n % 8 != 0) return -1;
   hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, in,

@@ -92,8 +92,7 @@ class DenseNetRef(tnn.Module):
                 tnn.init.constant_(m.bias, 0)
 
     def _stem(self, x):
-        x = to_device_input(x)
-        return conv_bn_relu_pool(self.conv0, self.norm0, self.pool0, x)
+        return conv_bn_relu_pool(self.conv0, self.norm0, self.pool0, x)       # converts the input itself
 
     def stages(self):
         """Logical layers for the model-parallel partitioner (the reference's layer ids, ``model.py:155-184``)."""

@@ -106,10 +106,9 @@ class ResNet(tnn.Module):
 
     # The stages below are what the model-parallel / pipeline wrappers split on.
     def stem(self, x):
-        x = to_device_input(x)
         if self.cifar_stem:
-            return conv_bn_act(self.conv1, self.bn1, x, relu=True)
-        return conv_bn_relu_pool(self.conv1, self.bn1, self.maxpool, x)
+            return conv_bn_act(self.conv1, self.bn1, to_device_input(x), relu=True)
+        return conv_bn_relu_pool(self.conv1, self.bn1, self.maxpool, x)       # converts the input itself
 
     def head(self, x):
         return self.fc(self.avgpool(x))

@@ -8,6 +8,7 @@ that is refreshed whenever the master changes (``Parameter._version`` or :func:`
 """
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
@@ -203,6 +204,15 @@ def conv_bn_act(conv: Conv2d, bn: BatchNorm2d, x, relu: bool = True, residual=No
     return bn(conv(x), residual=residual, relu=relu)
 
 
+_S2D_STEM = os.environ.get("DDL_S2D_STEM", "1") != "0"
+
+
+def _s2d_stem_ok(conv: Conv2d, x) -> bool:
+    return (_S2D_STEM and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3 and conv.in_channels == 3
+            and conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3)
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and not x.requires_grad and x.is_contiguous())
+
+
 def conv_bn_relu_pool(conv: Conv2d, bn: BatchNorm2d, pool, x):
     """conv -> BN -> ReLU -> max-pool (the ResNet / DenseNet stem).  In training on the GPU this is ONE fused unit
     whose full-resolution activation and gradient are never written (:class:`functional.ConvBNReluPool`)."""
@@ -211,6 +221,15 @@ def conv_bn_relu_pool(conv: Conv2d, bn: BatchNorm2d, pool, x):
               and not pool.ceil_mode and not pool.return_indices and 2 * p <= k and k * k < 255)
     if (simple and x.is_cuda and torch.is_grad_enabled() and bn.training and bn.track_running_stats and bn.affine
             and conv.bias is None and conv._native_ok() and conv.out_channels % 8 == 0):
+        if _s2d_stem_ok(conv, x):
+            # 7x7/2 stem on raw fp32 images: space-to-depth input + regrouped 4x4/1 filter (35 % shorter reduction
+            # forward, 4 filter rows of 64 columns instead of 7 x 56 in the filter gradient)
+            w2 = K.s2d_filter(conv.weight)
+            krsc = w2.detach().permute(0, 2, 3, 1).to(BF16).contiguous()
+            bn._count_batch()
+            return F.ConvBNReluPool.apply(K.nchw_to_s2d(x), w2, bn.weight, bn.bias, krsc, None, bn.running_mean,
+                                          bn.running_var, bn._momentum(), bn.eps, 1, 0, 16, bn.slabs(x.device),
+                                          (k, s, p))
         if x.shape[1] != _pad8(conv.in_channels):
             x = to_device_input(x)
         krsc, crsk = conv.packed()

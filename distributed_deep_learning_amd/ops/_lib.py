@@ -50,6 +50,7 @@ _SIGS = {
     "ddl_filter_transpose_batched": [_vp, _vp, _vp, _i, _i, _vp],
     "ddl_repack_desc_bytes": [],
     "ddl_nchw_to_nhwc_pad": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "ddl_nchw_to_s2d": [_vp, _vp, _i, _i, _i, _vp],
     "ddl_softmax_xent": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "ddl_chunk_elems": [],
     "ddl_flat_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

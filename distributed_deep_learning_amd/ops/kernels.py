@@ -439,6 +439,30 @@ def nchw_to_nhwc_pad(x: torch.Tensor, cp: int):
     return out
 
 
+def nchw_to_s2d(x: torch.Tensor):
+    """fp32 NCHW 3-channel images -> bf16 NHWC space-to-depth tensor ``[N, 16, H/2+3, W/2+3]`` (logical NCHW view)
+    with the stem's padding materialised; see ``csrc/eltwise.hip::nchw_to_s2d_kernel`` for the channel order."""
+    lib = _lib.require()
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    if Cc != 3 or x.dtype != torch.float32 or H % 2 or W % 2:
+        raise ValueError("nchw_to_s2d: needs fp32 [N,3,H,W] with even H and W")
+    out = torch.empty((N, 16, H // 2 + 3, W // 2 + 3), dtype=BF16, device=x.device, memory_format=CL)
+    check(lib.ddl_nchw_to_s2d(ptr(x), ptr(out), N, H, W, stream_ptr()), "nchw_to_s2d")
+    return out
+
+
+def s2d_filter(w: torch.Tensor) -> torch.Tensor:
+    """``[K,3,7,7]`` stem filter -> the equivalent ``[K,16,4,4]`` filter over :func:`nchw_to_s2d` input
+    (tap ``r = 2a + p``; the 8th tap and channels 12..15 are zero).  Plain differentiable torch ops: the filter
+    gradient flows back to the 7x7 parameter through autograd."""
+    K_ = w.shape[0]
+    w8 = torch.nn.functional.pad(w, (0, 1, 0, 1))                       # [K,3,8,8]
+    w8 = w8.reshape(K_, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4)        # [K, p, q, c, a, b]
+    w12 = w8.reshape(K_, 12, 4, 4)
+    return torch.nn.functional.pad(w12, (0, 0, 0, 0, 0, 4))             # [K,16,4,4]
+
+
 # ----------------------------------------------------------------------------------------------- recurrent
 def lstm_supported(hidden: int, inputs: int) -> bool:
     """Shapes with a compiled instance of the fused LSTM layer (constants mirrored from csrc/lstm.hip)."""

@@ -388,3 +388,47 @@ def test_lstm_layer_no_grad_and_fallbacks():
     odd = dnn.LSTM(20, 48).cuda()                   # no compiled instance -> stock path, fp32 out
     o2, _ = odd(torch.randn(4, 6, 20, device="cuda"))
     assert o2.dtype == torch.float32 and not odd.native_ok(torch.empty(4, 6, 20, device="cuda"))
+
+
+# ----------------------------------------------------------------------------------------------- space-to-depth stem
+@pytest.mark.gpu
+def test_s2d_stem_matches_direct_7x7_stem():
+    """7x7/2 stem as space-to-depth input + regrouped 4x4/1 filter == the direct stem: activations, filter / BN grads."""
+    from distributed_deep_learning_amd import nn as dnn
+    from distributed_deep_learning_amd.nn import modules as M
+    torch.manual_seed(5)
+    x = torch.randn(6, 3, 64, 48, device="cuda")
+    gout = None
+    res = {}
+    for tag, flag in (("direct", False), ("s2d", True)):
+        torch.manual_seed(9)
+        conv = dnn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+        bn = dnn.BatchNorm2d(64).cuda()
+        pool = dnn.MaxPool2d(3, 2, 1)
+        M._S2D_STEM = flag
+        try:
+            y = M.conv_bn_relu_pool(conv, bn, pool, x)
+        finally:
+            M._S2D_STEM = True
+        if gout is None:
+            gout = torch.randn_like(y.float()).to(y.dtype)
+        y.backward(gout)
+        res[tag] = (y.float(), conv.weight.grad.float().clone(), bn.weight.grad.float().clone(), bn.bias.grad.float().clone())
+    # fp32 reference of the same unit
+    torch.manual_seed(9)
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    bn = torch.nn.BatchNorm2d(64).cuda()
+    yr = torch.nn.functional.max_pool2d(torch.relu(bn(conv(x))), 3, 2, 1)
+    yr.backward(gout.float())
+
+    def rel(a, b):
+        return float((a - b).norm() / (b.norm() + 1e-12))
+
+    assert res["s2d"][0].shape == yr.shape
+    assert rel(res["s2d"][0], yr.detach()) < 2e-2
+    # same bf16 operands, same fp32 accumulation: the two formulations agree to rounding of the summation order
+    assert rel(res["s2d"][0], res["direct"][0]) < 1e-2 and rel(res["s2d"][1], res["direct"][1]) < 1e-3
+    # against fp32 the filter gradient carries the bf16 noise of the BN-backward input (8 % on this tiny sample,
+    # uniform over the 49 taps, identical for both formulations)
+    assert rel(res["s2d"][1], conv.weight.grad) < 0.15
+    assert rel(res["s2d"][2], bn.weight.grad) < 5e-2 and rel(res["s2d"][3], bn.bias.grad) < 5e-2
