@@ -145,14 +145,22 @@ template <bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ res,
                                                        bf16_t* __restrict__ y, unsigned char* __restrict__ mask,
                                                        const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, RowMap rm) {
+                                                       const float* __restrict__ shift,
+                                                       const float* __restrict__ res_scale,
+                                                       const float* __restrict__ res_shift, RowMap rm) {
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
   const int chunk = blockIdx.y * rm.cpb + col;
   if (rg >= rm.rp || chunk >= rm.c8) return;
-  float sc[8], sh[8];
+  float sc[8], sh[8], rsc[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { sc[q] = scale[chunk * 8 + q]; sh[q] = shift[chunk * 8 + q]; }
+  for (int q = 0; q < 8; ++q) { sc[q] = scale[chunk * 8 + q]; sh[q] = shift[chunk * 8 + q]; rsc[q] = 1.f; }
+  // Projection shortcut: the residual is the RAW output of the shortcut conv and its BN affine is applied here
+  // (res_scale / res_shift), so the normalised shortcut tensor is never written or re-read.
+  if (RES && res_scale != nullptr) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { rsc[q] = res_scale[chunk * 8 + q]; sh[q] += res_shift[chunk * 8 + q]; }
+  }
   // Rows are walked from the END of the tensor: the producer (conv epilogue / reduce pass) touched the tail last, so
   // that part is still in the 256 MB memory-side cache when this pass starts.
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
       float r[8];
       unpack8(rv, r);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) f[q] += r[q];
+      for (int q = 0; q < 8; ++q) f[q] += r[q] * rsc[q];
     }
     if (RELU) {
       if (mask != nullptr) {                  // 1 bit per element: the backward reads this instead of y
@@ -408,19 +416,22 @@ extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, cons
 
 // mask (optional, only written when relu): [M][C/8] bytes, bit q of byte (row, chunk) = (y[row][chunk*8+q] > 0)
 extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
-                            const float* shift, int M, int C, int relu, void* stream) {
+                            const float* shift, const float* res_scale, const float* res_shift, int M, int C, int relu,
+                            void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
+  if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale != nullptr && res == nullptr)) return -2;
+  const float* rs = res_scale; const float* rh = res_shift;
   const RowMap rm = make_rowmap(M, C);
   const dim3 grid = rowmap_grid(rm, apply_grid_cap());
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* xp = (const bf16_t*)x; const bf16_t* rp = (const bf16_t*)res; bf16_t* yp = (bf16_t*)y;
   unsigned char* mp = (unsigned char*)mask;
   if (res != nullptr) {
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
-    else      hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<true, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rs, rh, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<true, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rs, rh, rm);
   } else {
-    if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
-    else      hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rm);
+    if (relu) hipLaunchKernelGGL((bn_apply_kernel<false, true>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rs, rh, rm);
+    else      hipLaunchKernelGGL((bn_apply_kernel<false, false>), grid, dim3(256), 0, st, xp, rp, yp, mp, scale, shift, rs, rh, rm);
   }
   return (int)hipGetLastError();
 }

@@ -148,7 +148,7 @@ class ResidualBlock(torch.autograd.Function):
         x = K.nhwc(_bf16(x))
         saved, metas = [], []
 
-        def run(conv, bn, inp, relu, residual):
+        def run(conv, bn, inp, relu, residual, res_affine=None, apply=True):
             krsc, crsk = conv.packed()
             slabs = bn.slabs(inp.device)
             bn._count_batch()
@@ -157,18 +157,25 @@ class ResidualBlock(torch.autograd.Function):
             vec = K.bn_finalize(stats, n * p_ * q_, bn.weight, bn.bias, bn.running_mean, bn.running_var,
                                 bn._momentum(), bn.eps)
             rows = K.vec_rows(vec)
-            out, mask = K.bn_apply(y_conv, rows[2], rows[3], residual=residual, relu=relu, want_mask=True)
+            out = mask = None
+            if apply:
+                rs, rh = res_affine if res_affine is not None else (None, None)
+                out, mask = K.bn_apply(y_conv, rows[2], rows[3], residual=residual, relu=relu, want_mask=True,
+                                       res_scale=rs, res_shift=rh)
             saved.extend([inp, y_conv, mask, vec, crsk])
             metas.append((conv, bn, relu, residual is not None, slabs[1]))
-            return out
+            return out if apply else (y_conv, rows[2], rows[3])
 
-        identity = x
+        identity, ds_affine = x, None
         if ds is not None:
-            identity = run(ds[0], ds[1], x, False, None)
+            # projection shortcut: only conv + statistics here; its BN affine is applied to the raw conv output inside
+            # the last unit's apply pass, so the normalised shortcut is neither written nor read back
+            identity, sc, sh = run(ds[0], ds[1], x, False, None, apply=False)
+            ds_affine = (sc, sh)
         h = x
         for i, (conv, bn) in enumerate(units):
             last = i == len(units) - 1
-            h = run(conv, bn, h, True, identity if last else None)
+            h = run(conv, bn, h, True, identity if last else None, ds_affine if last else None)
         ctx.save_for_backward(*saved)
         ctx.metas = metas
         ctx.has_ds = ds is not None

@@ -181,9 +181,11 @@ def vec_rows(vec):
     return v0, v0 + row, v0 + 2 * row, v0 + 3 * row
 
 
-def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False):
+def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False, res_scale=None, res_shift=None):
     """y = act(x*scale + shift [+ residual]).  With ``want_mask`` also returns the 1-bit-per-element ReLU mask
-    (``uint8 [N*H*W, C/8]``) that :func:`bn_backward` consumes instead of re-reading ``y``."""
+    (``uint8 [N*H*W, C/8]``) that :func:`bn_backward` consumes instead of re-reading ``y``.  ``res_scale`` /
+    ``res_shift`` (fp32 ``[C]``): the residual enters as ``residual*res_scale + res_shift`` — a projection shortcut's
+    BN applied on the fly to the raw shortcut-conv output."""
     lib = _lib.require()
     _chk_act(x, "bn_apply")
     x = nhwc(x)
@@ -195,8 +197,8 @@ def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False):
             raise ValueError("bn_apply: residual shape mismatch")
     y = torch.empty_like(x, memory_format=CL)
     mask = torch.empty((N * H * W, Cc // 8), dtype=torch.uint8, device=x.device) if (want_mask and relu) else None
-    check(lib.ddl_bn_apply(ptr(x), ptr(residual), ptr(y), ptr(mask), ptr(scale), ptr(shift), N * H * W, Cc, int(relu),
-                           stream_ptr()), "bn_apply")
+    check(lib.ddl_bn_apply(ptr(x), ptr(residual), ptr(y), ptr(mask), ptr(scale), ptr(shift), ptr(res_scale),
+                           ptr(res_shift), N * H * W, Cc, int(relu), stream_ptr()), "bn_apply")
     return (y, mask) if want_mask else y
 
 
