@@ -394,6 +394,115 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// ---------------------------------------------------------------- backward of TWO BatchNorms behind one gradient
+// A projection block ends in  out = relu(BN_a(z_a) + BN_b(z_b))  (last main-path BN + shortcut BN): both backward
+// passes consume the same dy and the same ReLU mask.  These variants read them ONCE per pass for both normalisations.
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                             const bf16_t* __restrict__ xa, const bf16_t* __restrict__ xb,
+                                                             const float* __restrict__ mean_a, const float* __restrict__ invstd_a,
+                                                             const float* __restrict__ mean_b, const float* __restrict__ invstd_b,
+                                                             float* __restrict__ slab_a, float* __restrict__ slab_b, RowMap rm) {
+  __shared__ float red[256 * 24];
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  const bool active = (rg < rm.rp) && (chunk < rm.c8);
+  float s1[8], sa[8], sb[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; sa[q] = 0.f; sb[q] = 0.f; }
+  if (active) {
+    float mua[8], isa[8], mub[8], isb[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      mua[q] = mean_a[chunk * 8 + q]; isa[q] = invstd_a[chunk * 8 + q];
+      mub[q] = mean_b[chunk * 8 + q]; isb[q] = invstd_b[chunk * 8 + q];
+    }
+    for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
+      const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
+      const u32x4 av = ld_stream(xa + off);
+      const u32x4 bv = ld_stream(xb + off);
+      const u32x4 gv = ld_stream(dy + off);
+      float g[8], fa[8], fb[8];
+      unpack8(av, fa); unpack8(bv, fb); unpack8(gv, g);
+      if (RELU) {
+        const unsigned m = mask[(size_t)row * rm.c8 + chunk];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        s1[q] += g[q];
+        sa[q] += g[q] * (fa[q] - mua[q]) * isa[q];
+        sb[q] += g[q] * (fb[q] - mub[q]) * isb[q];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) { red[tid * 24 + q] = s1[q]; red[tid * 24 + 8 + q] = sa[q]; red[tid * 24 + 16 + q] = sb[q]; }
+  __syncthreads();
+  const int nout = rm.cpb * 24;
+  for (int o = tid; o < nout; o += 256) {
+    const int c = o / 24, e = o % 24;
+    const int ch = blockIdx.y * rm.cpb + c;
+    if (ch >= rm.c8) continue;
+    float s = 0.f;
+    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 24 + e];
+    const int which = e >> 3, q = e & 7;
+    const int slot = blockIdx.x % BN_SLOTS;
+    const size_t cidx = (size_t)ch * 8 + q;
+    if (which == 0) {                                   // sum(g) belongs to both
+      atomicAdd(&slab_a[((size_t)slot * 2) * rm.C + cidx], s);
+      atomicAdd(&slab_b[((size_t)slot * 2) * rm.C + cidx], s);
+    } else if (which == 1) {
+      atomicAdd(&slab_a[((size_t)slot * 2 + 1) * rm.C + cidx], s);
+    } else {
+      atomicAdd(&slab_b[((size_t)slot * 2 + 1) * rm.C + cidx], s);
+    }
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                            const bf16_t* __restrict__ xa, const bf16_t* __restrict__ xb,
+                                                            bf16_t* __restrict__ dxa, bf16_t* __restrict__ dxb,
+                                                            const float* __restrict__ coef_a, const float* __restrict__ coef_b,
+                                                            RowMap rm) {
+  const int tid = threadIdx.x;
+  const int col = tid % rm.cpb, rg = tid / rm.cpb;
+  const int chunk = blockIdx.y * rm.cpb + col;
+  if (rg >= rm.rp || chunk >= rm.c8) return;
+  float aa[8], ab[8], ac[8], ba[8], bb[8], bc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int c = chunk * 8 + q;
+    aa[q] = coef_a[c]; ab[q] = coef_a[rm.C + c]; ac[q] = coef_a[2 * rm.C + c];
+    ba[q] = coef_b[c]; bb[q] = coef_b[rm.C + c]; bc[q] = coef_b[2 * rm.C + c];
+  }
+  for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
+    const int row = rm.M - 1 - r0;
+    const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
+    const u32x4 av = ld_stream(xa + off);
+    const u32x4 bv = ld_stream(xb + off);
+    const u32x4 gv = ld_stream(dy + off);
+    float g[8], fa[8], fb[8];
+    unpack8(av, fa); unpack8(bv, fb); unpack8(gv, g);
+    if (RELU) {
+      const unsigned m = mask[(size_t)row * rm.c8 + chunk];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) g[q] = ((m >> q) & 1u) ? g[q] : 0.f;
+    }
+    float oa[8], ob[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      oa[q] = aa[q] * g[q] + ab[q] * fa[q] + ac[q];
+      ob[q] = ba[q] * g[q] + bb[q] * fb[q] + bc[q];
+    }
+    *reinterpret_cast<u32x4*>(dxa + off) = pack8(oa);
+    *reinterpret_cast<u32x4*>(dxb + off) = pack8(ob);
+  }
+}
+
 // ================================================================ C ABI
 extern "C" int ddl_bn_slots() { return BN_SLOTS; }
 
@@ -460,6 +569,33 @@ extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, 
     if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<false, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
     else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   }
+  return (int)hipGetLastError();
+}
+
+// Backward of two BatchNorms sharing dy (+ mask): see bn_bwd_reduce2_kernel.  Every per-BN argument comes as a / b.
+extern "C" int ddl_bn_backward_pair(const void* dy, const void* mask, const void* xa, const void* xb,
+                                    const float* gamma_a, const float* mean_a, const float* invstd_a,
+                                    const float* gamma_b, const float* mean_b, const float* invstd_b, void* dxa, void* dxb,
+                                    float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, float* slab_a,
+                                    float* slab_b, float* coef_a, float* coef_b, int M, int C, int relu, int accumulate,
+                                    void* stream) {
+  if (C % 8 != 0 || M <= 0) return -1;
+  if (relu && mask == nullptr) return -2;
+  if (slab_a == slab_b || coef_a == coef_b || dxa == dxb) return -3;
+  hipStream_t st = (hipStream_t)stream;
+  const RowMap rm = make_rowmap(M, C);
+  const dim3 grid = rowmap_grid(rm);
+  const bf16_t* dyp = (const bf16_t*)dy; const unsigned char* mp = (const unsigned char*)mask;
+  const bf16_t* ap = (const bf16_t*)xa; const bf16_t* bp = (const bf16_t*)xb;
+  if (relu) hipLaunchKernelGGL((bn_bwd_reduce2_kernel<true>), grid, dim3(256), 0, st, dyp, mp, ap, bp, mean_a, invstd_a, mean_b, invstd_b, slab_a, slab_b, rm);
+  else      hipLaunchKernelGGL((bn_bwd_reduce2_kernel<false>), grid, dim3(256), 0, st, dyp, mp, ap, bp, mean_a, invstd_a, mean_b, invstd_b, slab_a, slab_b, rm);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab_a, BN_SLOTS, C, (float)M, gamma_a,
+                     mean_a, invstd_a, dgamma_a, dbeta_a, accumulate, coef_a, coef_a + C, coef_a + 2 * (size_t)C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab_b, BN_SLOTS, C, (float)M, gamma_b,
+                     mean_b, invstd_b, dgamma_b, dbeta_b, accumulate, coef_b, coef_b + C, coef_b + 2 * (size_t)C);
+  const dim3 agrid = rowmap_grid(rm, apply_grid_cap());
+  if (relu) hipLaunchKernelGGL((bn_bwd_apply2_kernel<true>), agrid, dim3(256), 0, st, dyp, mp, ap, bp, (bf16_t*)dxa, (bf16_t*)dxb, coef_a, coef_b, rm);
+  else      hipLaunchKernelGGL((bn_bwd_apply2_kernel<false>), agrid, dim3(256), 0, st, dyp, mp, ap, bp, (bf16_t*)dxa, (bf16_t*)dxb, coef_a, coef_b, rm);
   return (int)hipGetLastError();
 }
 

@@ -9,6 +9,8 @@ Reference parity: these cover the implicit device ops of the reference's trainin
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from ..ops import kernels as K
@@ -58,6 +60,30 @@ def _bn_bwd(dout, mask, x_bn, gamma_p, beta_p, gamma, mean, invstd, relu, want_d
         arena.notify_grad_ready(beta_p)
         dgamma = dbeta = None
     return dx, dres, dgamma, dbeta
+
+
+_PAIR_BN = os.environ.get("DDL_BN_PAIR", "1") != "0"
+
+
+def _bn_bwd_pair(dout, mask, saved, metas, ia, ib):
+    """BN backward of units ``ia`` and ``ib`` of a residual block, both fed by ``dout`` behind ``mask``.
+    Returns ``(dconv, dgamma, dbeta)`` per unit (gradients ``None`` when they went straight into the arena)."""
+    _, ya, _, va, _ = saved[5 * ia:5 * ia + 5]
+    _, yb, _, vb, _ = saved[5 * ib:5 * ib + 5]
+    bna, bnb = metas[ia][1], metas[ib][1]
+    ra, rb = K.vec_rows(va), K.vec_rows(vb)
+    arena_a, gout_a = _bn_grad_out(bna.weight, bna.bias)
+    arena_b, gout_b = _bn_grad_out(bnb.weight, bnb.bias)
+    both = arena_a is not None and arena_b is not None
+    dxa, dxb, ga, gb = K.bn_backward_pair(dout, mask, ya, yb, (bna.weight, ra[0], ra[1]), (bnb.weight, rb[0], rb[1]),
+                                          relu=True, slabs=(metas[ia][4], metas[ib][4]),
+                                          grad_outs=(gout_a, gout_b) if both else None)
+    if both:
+        for arena, bn in ((arena_a, bna), (arena_b, bnb)):
+            arena.notify_grad_ready(bn.weight)
+            arena.notify_grad_ready(bn.bias)
+        return (dxa, None, None), (dxb, None, None)
+    return (dxa, ga[0], ga[1]), (dxb, gb[0], gb[1])
 
 
 class ConvBNAct(torch.autograd.Function):
@@ -189,7 +215,7 @@ class ResidualBlock(torch.autograd.Function):
         grads = {}
 
         def back(idx, dy, need_dx, addend=None, addend_mask=None, relu_mask=None, want_dres=False, addend_step=1,
-                 compact_dx=False):
+                 compact_dx=False, bn_done=None):
             """BN(+ReLU) backward -> dgrad (+ addend) -> wgrad of unit ``idx``.  ``relu_mask`` overrides the unit's
             own activation: the unit then sees ``dy * mask`` (used to push the block-output ReLU into the shortcut)."""
             inp, y_conv, mask, vec, crsk = saved[5 * idx:5 * idx + 5]
@@ -197,8 +223,12 @@ class ResidualBlock(torch.autograd.Function):
             if relu_mask is not None:
                 relu, mask = True, relu_mask
             rows = K.vec_rows(vec)
-            dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
-                                                 relu, want_dres, slab)
+            if bn_done is not None:                  # BN backward already ran (paired with another unit's)
+                dconv, dgamma, dbeta = bn_done
+                dres = None
+            else:
+                dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
+                                                     relu, want_dres, slab)
             dx = None
             if need_dx and compact_dx:
                 # strided 1x1 conv: its input gradient is non-zero only on the stride grid -> compute just that grid
@@ -221,7 +251,13 @@ class ResidualBlock(torch.autograd.Function):
         if last > first_main:
             # The shortcut's gradient is dout * relu'(out).  It is never written: the projection's BN backward and the
             # first conv's dgrad epilogue apply the block-output mask to ``dout`` themselves.
-            d, _ = back(last, dout, True)
+            ds_done = None
+            if ctx.has_ds and _PAIR_BN:
+                # last main BN and shortcut BN see the same gradient behind the same mask: one pair of passes
+                last_done, ds_done = _bn_bwd_pair(dout, out_mask, saved, metas, last, 0)
+                d, _ = back(last, dout, True, bn_done=last_done)
+            else:
+                d, _ = back(last, dout, True)
             for idx in range(last - 1, first_main, -1):
                 d, _ = back(idx, d, True)
             if ctx.has_ds:
@@ -230,7 +266,7 @@ class ResidualBlock(torch.autograd.Function):
                 fconv = metas[first_main][0]
                 compact = (step > 1 and dsc.kernel_size == (1, 1) and dsc.padding[0] == 0
                            and fconv.stride[0] == 1)          # first main conv writes every input pixel in one launch
-                dshort, _ = back(0, dout, need_x, relu_mask=out_mask, compact_dx=compact)
+                dshort, _ = back(0, dout, need_x, relu_mask=out_mask, compact_dx=compact, bn_done=ds_done)
                 dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None,
                              addend_step=step if compact else 1)
             else:

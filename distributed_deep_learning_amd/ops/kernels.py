@@ -229,6 +229,42 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
     return dx, dres, dgb[0], dgb[1]
 
 
+def bn_backward_pair(dy, mask, xa, xb, stat_a, stat_b, relu=True, slabs=None, grad_outs=None):
+    """Backward of two BatchNorms fed by the same gradient ``dy`` (and ReLU ``mask``): a projection block's last BN
+    (input ``xa``) and its shortcut BN (``xb``).  ``stat_x = (gamma, mean, invstd)``; ``slabs`` / ``grad_outs`` as in
+    :func:`bn_backward`, one per BN.  ``dy`` and the mask are read once per pass for both.
+    Returns ``(dxa, dxb, (dgamma_a, dbeta_a), (dgamma_b, dbeta_b))``."""
+    lib = _lib.require()
+    _chk_act(dy, "bn_backward_pair")
+    dy, xa, xb = nhwc(dy), nhwc(xa), nhwc(xb)
+    if xa.shape != xb.shape or dy.shape != xa.shape:
+        raise ValueError("bn_backward_pair: dy / xa / xb shapes differ")
+    N, Cc, H, W = xa.shape
+    if relu and (mask is None or mask.dtype != torch.uint8 or mask.numel() != N * H * W * Cc // 8):
+        raise ValueError("bn_backward_pair: relu=True needs the uint8 [N*H*W, C/8] mask from bn_apply(want_mask=True)")
+    dxa = torch.empty_like(xa, memory_format=CL)
+    dxb = torch.empty_like(xb, memory_format=CL)
+    acc = grad_outs is not None
+    if acc:
+        for dg, db in grad_outs:
+            if not (dg.is_contiguous() and db.is_contiguous() and dg.numel() == Cc and db.numel() == Cc
+                    and dg.dtype == torch.float32 and db.dtype == torch.float32):
+                raise ValueError("bn_backward_pair: grad_outs must be pairs of contiguous fp32 [C] tensors")
+        ga, gb = grad_outs
+    else:
+        t = torch.empty((4, Cc), dtype=torch.float32, device=xa.device)
+        ga, gb = (t[0], t[1]), (t[2], t[3])
+    sa, sb = slabs if slabs is not None else (new_slab(Cc, xa.device), new_slab(Cc, xa.device))
+    scratch = _lib.bn_slots() * 2 * Cc * 4
+    check(lib.ddl_bn_backward_pair(ptr(dy), ptr(mask) if relu else None, ptr(xa), ptr(xb),
+                                   ptr(stat_a[0]), ptr(stat_a[1]), ptr(stat_a[2]),
+                                   ptr(stat_b[0]), ptr(stat_b[1]), ptr(stat_b[2]), ptr(dxa), ptr(dxb),
+                                   ptr(ga[0]), ptr(ga[1]), ptr(gb[0]), ptr(gb[1]), ptr(sa), ptr(sb),
+                                   sa.data_ptr() + scratch, sb.data_ptr() + scratch, N * H * W, Cc, int(relu), int(acc),
+                                   stream_ptr()), "bn_backward_pair")
+    return dxa, dxb, ga, gb
+
+
 def bn_relu_maxpool_fwd(x, scale, shift, k, stride, pad):
     """``maxpool(relu(x*scale + shift))`` straight from the conv output ``x``: returns ``(y_pool, idx)`` — the
     full-resolution activation is never written.  ``idx`` (uint8, shape of ``y_pool``) feeds

@@ -432,3 +432,40 @@ def test_s2d_stem_matches_direct_7x7_stem():
     # uniform over the 49 taps, identical for both formulations)
     assert rel(res["s2d"][1], conv.weight.grad) < 0.15
     assert rel(res["s2d"][2], bn.weight.grad) < 5e-2 and rel(res["s2d"][3], bn.bias.grad) < 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 64, 14, 14), (3, 256, 9, 7), (2, 24, 5, 5)])
+def test_bn_backward_pair_equals_two_single_backwards(shape):
+    """Paired BN backward (one read of dy + mask for a block's last BN and its shortcut BN) == two bn_backward calls,
+    both with fresh outputs and accumulating into existing gradient vectors."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W = shape
+    xa = _rand_act(shape, 21, scale=2.0) + 0.5
+    xb = _rand_act(shape, 22, scale=0.7) - 0.2
+    g = torch.Generator().manual_seed(23)
+    stats = []
+    for x in (xa, xb):
+        gamma = (torch.rand(C, generator=g) + 0.5).to(_dev())
+        beta = (torch.randn(C, generator=g) * 0.1).to(_dev())
+        vec = K.bn_finalize(K.bn_stats(x), N * H * W, gamma, beta, torch.zeros(C, device=_dev()), torch.ones(C, device=_dev()),
+                            0.1, 1e-5)
+        stats.append((gamma, vec))
+    (ga, va), (gb, vb) = stats
+    y, mask = K.bn_apply(xa, va[2], va[3], residual=xb, relu=True, want_mask=True, res_scale=vb[2], res_shift=vb[3])
+    ref_y = torch.relu(xa.float() * va[2].view(1, -1, 1, 1) + va[3].view(1, -1, 1, 1)
+                       + xb.float() * vb[2].view(1, -1, 1, 1) + vb[3].view(1, -1, 1, 1))
+    _close(y, ref_y, what="dual-affine apply")
+    dy = _rand_act(shape, 24)
+    one_a = K.bn_backward(dy, mask, xa, ga, va[0], va[1], relu=True)
+    one_b = K.bn_backward(dy, mask, xb, gb, vb[0], vb[1], relu=True)
+    dxa, dxb, gra, grb = K.bn_backward_pair(dy, mask, xa, xb, (ga, va[0], va[1]), (gb, vb[0], vb[1]))
+    assert torch.equal(dxa, one_a[0]) or (dxa.float() - one_a[0].float()).abs().max() < 2e-2
+    assert torch.equal(dxb, one_b[0]) or (dxb.float() - one_b[0].float()).abs().max() < 2e-2
+    for got, want in ((gra[0], one_a[2]), (gra[1], one_a[3]), (grb[0], one_b[2]), (grb[1], one_b[3])):
+        _close(got, want, rtol=1e-4, atol=1e-3 * max(1.0, float(want.abs().max())), what="pair dgamma/dbeta")
+    # accumulate mode: adds to what is already there
+    acc = [torch.full((C,), 2.0, device=_dev()) for _ in range(4)]
+    K.bn_backward_pair(dy, mask, xa, xb, (ga, va[0], va[1]), (gb, vb[0], vb[1]), grad_outs=((acc[0], acc[1]), (acc[2], acc[3])))
+    for got, want in zip(acc, (one_a[2], one_a[3], one_b[2], one_b[3])):
+        _close(got - 2.0, want, rtol=1e-4, atol=1e-3 * max(1.0, float(want.abs().max())), what="pair accumulate")
