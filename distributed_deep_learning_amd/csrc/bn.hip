@@ -340,11 +340,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate, float* __restrict__ coefA,
-                                       float* __restrict__ coefB, float* __restrict__ coefC) {
+                                       float* __restrict__ coefB, float* __restrict__ coefC, int raw = 0) {
   float sg, sgx;
   slab_fold(slab, nslots, C, sg, sgx);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || c >= C) return;
+  // raw: the slab holds sum(g), sum(g*x) from a dgrad epilogue (conv_epilogue.h) instead of sum(g*xhat)
+  if (raw) sgx = invstd[c] * (sgx - mean[c] * sg);
   if (accumulate) { dgamma[c] += sgx; dbeta[c] += sg; }      // straight into the arena gradient
   else            { dgamma[c] = sgx;  dbeta[c] = sg; }
   const float g = gamma ? gamma[c] : 1.f;
@@ -548,18 +550,21 @@ extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask,
 // Full backward.  slab must be ZERO on entry (it is left zero again).  mask: the [M][C/8] ReLU bit mask written by ddl_bn_apply (required when relu).  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
 extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, const float* gamma, const float* mean,
                                const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
-                               float* coef, int M, int C, int relu, int accumulate, void* stream) {
+                               float* coef, int M, int C, int relu, int accumulate, int presummed, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
   const RowMap rm = make_rowmap(M, C);
   const dim3 grid = rowmap_grid(rm);
   const bf16_t* dyp = (const bf16_t*)dy; const unsigned char* yp = (const unsigned char*)mask; const bf16_t* xp = (const bf16_t*)x;
   if (relu && mask == nullptr) return -2;
-  if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
-  else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
+  // presummed: the producer of dy (a dgrad epilogue) already left sum(g), sum(g*x) in the slab: no reduction pass
+  if (!presummed) {
+    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
+    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
+  }
   float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
-                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
+                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC, presummed ? 1 : 0);
   bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
   const dim3 agrid = rowmap_grid(rm, apply_grid_cap());
   if (relu) {

@@ -94,7 +94,20 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
         vo = pack8(f);
       }
       *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
-      if (EPI & 2) {
+      if ((EPI & 2) && MODE == 1) {
+        // BN-backward sums for the BatchNorm behind this gradient: g = (stored, bf16-rounded) dx behind the ReLU mask
+        float g[8], z[8];
+        unpack8(vo, g);
+        const u32x4 zv = *reinterpret_cast<const u32x4*>(p.bnz + opix * (size_t)p.OC + (size_t)ncol);
+        unpack8(zv, z);
+        if (p.bnz_mask != nullptr) {
+          const unsigned mk = p.bnz_mask[opix * (size_t)(p.OC >> 3) + (size_t)(ncol >> 3)];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g[q] = ((mk >> q) & 1u) ? g[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * z[q]; }
+      } else if (EPI & 2) {
         float f[8];
         unpack8(v, f);
 #pragma unroll

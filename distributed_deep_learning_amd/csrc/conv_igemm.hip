@@ -301,8 +301,10 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   static const int use_ring = [] { const char* e = getenv("DDL_CONV_RING"); return e ? atoi(e) : 1; }();
   p.mode_hint = MODE;
   p.trace = g_conv_trace;
-  if (use_ring && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
+  const bool bwd_sums = MODE == 1 && p.stats != nullptr;
+  if (use_ring && !bwd_sums && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
+  if (bwd_sums) return -9;                                     // only the ring kernel's epilogue takes these sums
   p.tiles_m = (p.M + 127) / 128;
   static const int force64 = [] { const char* e = getenv("DDL_CONV_BN64"); return e ? atoi(e) : 0; }();
   if (p.OC <= 64 || force64) {
@@ -314,7 +316,8 @@ static int launch_any(ConvParams& p, hipStream_t st) {
 }
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
-                              const void* addend, const void* addend_mask, int addend_step, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              const void* addend, const void* addend_mask, int addend_step, const void* bnz,
+                              const void* bnz_mask, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
@@ -328,7 +331,10 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   if (addend_step < 1 || (addend_step > 1 && addend_mask != nullptr)) return -8;
   p.addend_step = addend != nullptr ? addend_step : 1;
   p.AH = (OH + addend_step - 1) / addend_step; p.AW = (OW + addend_step - 1) / addend_step;
-  if (addend != nullptr && stats != nullptr) return -5;      // statistics are taken before the addend
+  if (mode == 0 && addend != nullptr && stats != nullptr) return -5;   // forward statistics: of the raw conv output
+  if (mode == 0 && (bnz != nullptr || bnz_mask != nullptr)) return -10;
+  if (mode == 1 && ((stats != nullptr) != (bnz != nullptr) || (bnz_mask != nullptr && bnz == nullptr))) return -10;
+  p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask;
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;
@@ -349,7 +355,7 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
       const int r0 = (ph + pad) % stride, s0 = (pw + pad) % stride;
       if (r0 >= R || s0 >= S || ph >= OH || pw >= OW) { any_empty = true; break; }
     }
-  if (any_empty && addend != nullptr) return -4;             // the zero-filled pixels would miss the addend
+  if (any_empty && (addend != nullptr || stats != nullptr)) return -4;   // zero-filled pixels would miss the epilogue
   if (any_empty) {   // classes without a contributing tap (e.g. 1x1 stride-2) are plain zeros
     hipError_t e = hipMemsetAsync(out, 0, sizeof(bf16_t) * (size_t)M * (size_t)OC, st);
     if (e != hipSuccess) return (int)e;

@@ -23,6 +23,11 @@ struct ConvParams {
   unsigned long long in_bytes, w_bytes;
   FastDiv div_ohw, div_ow;
   long long* trace;                       // debug: [block][4] wall-clock stamps (start, loop begin, loop end, end) or null
+  // dgrad only, with `stats`: BN-backward partial sums of the BatchNorm whose activation this dgrad differentiates.
+  // bnz = that BN's input (raw conv output, geometry of `out`), bnz_mask = its ReLU bit mask (null: no ReLU).
+  // The epilogue adds  sum(g), sum(g * z)  with  g = out * mask  into the stats slab.
+  const bf16_t* bnz;
+  const unsigned char* bnz_mask;
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 

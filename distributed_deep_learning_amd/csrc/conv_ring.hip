@@ -243,6 +243,8 @@ int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
     if (p.bias != nullptr || p.relu) return launch_ring<BN, BK, 0, 1>(p, stream);
     return launch_ring<BN, BK, 0, 0>(p, stream);
   }
+  if (p.stats != nullptr)      // BN-backward sums of the consumer BatchNorm (needs bnz), after the addend
+    return p.addend != nullptr ? launch_ring<BN, BK, 1, 6>(p, stream) : launch_ring<BN, BK, 1, 2>(p, stream);
   if (p.addend != nullptr) return launch_ring<BN, BK, 1, 4>(p, stream);
   return launch_ring<BN, BK, 1, 0>(p, stream);
 }
@@ -261,7 +263,7 @@ int ring_bk(const ConvParams& p) {
 
 // 32-bit byte offsets inside both operands, and room for the out-of-range sentinel above them.
 bool ddl_conv_ring_supported(const ConvParams& p) {
-  if (p.mode_hint == 1 && (p.bias != nullptr || p.relu || p.stats != nullptr)) return false;
+  if (p.mode_hint == 1 && (p.bias != nullptr || p.relu || (p.stats != nullptr && p.bnz == nullptr))) return false;
   if (p.mode_hint == 0 && p.addend != nullptr) return false;
   if (p.stats != nullptr && (p.bias != nullptr || p.relu)) return false;
   return p.in_bytes < 0xFFFF0000ull && p.w_bytes < 0xFFFF0000ull;

@@ -23,7 +23,7 @@ _load_error: Exception | None = None
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 _SIGS = {
-    "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp] + [_i] * 13 + [_vp],
+    "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 12 + [_vp],
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_spin": [_ll, _vp],
@@ -31,7 +31,7 @@ _SIGS = {
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
     "ddl_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _i, _vp],
+    "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _i, _i, _vp],
     "ddl_bn_backward_pair": [_vp] * 20 + [_i, _i, _i, _i, _vp],
     "ddl_bn_relu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp],
     "ddl_bn_relu_maxpool_bwd": [_vp] * 11 + [_i] * 10 + [_vp],

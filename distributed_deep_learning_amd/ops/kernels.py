@@ -80,20 +80,28 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
         raise TypeError("conv2d_fwd: bias must be fp32 [K]")
-    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, 1, N, P, Q, H, W, Cc, K,
-                             R, S,
-                             stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
+    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, 1, None, None,
+                             N, P, Q, H, W, Cc, K, R, S, stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
     return y, stats
 
 
-def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None, addend_step=1):
+def dgrad_bn_sums_ok(dy, w_crsk, stride, R, S) -> bool:
+    """Whether :func:`conv2d_dgrad` can take ``bn_sums`` for this problem (ring kernel: 32-bit operand offsets; every
+    input pixel produced by a launch, which excludes strides larger than the filter)."""
+    return dy.numel() * 2 < 0xFFFF0000 and w_crsk.numel() * 2 < 0xFFFF0000 and (stride == 1 or (R >= stride and S >= stride))
+
+
+def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None, addend_step=1, bn_sums=None):
     """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC).
     ``addend`` (bf16, shape of dx) is added in the epilogue: gradient accumulation of a second path for free.
     ``addend_mask`` (uint8 ``[N*H*W, C/8]``, the ReLU bit mask :func:`bn_apply` writes) zeroes the addend where its
     bit is clear: ``dx = dgrad + addend * mask`` — the residual-branch gradient ``dy * relu'(y)`` without ever
     materialising it.  ``addend_step`` s > 1: the addend is COMPACT ``[N, C, ceil(H/s), ceil(W/s)]`` and is added at
     pixels ``(h, w)`` with ``h % s == w % s == 0`` only — the input gradient of a strided 1x1 projection shortcut,
-    which is zero everywhere else, without the zero-filled full-size tensor."""
+    which is zero everywhere else, without the zero-filled full-size tensor.
+    ``bn_sums = (z, mask or None, slab)``: dx is the gradient of ``act(BN(z))`` (``z`` bf16, shape of dx; ``mask`` its
+    ReLU bit mask); the epilogue accumulates that BatchNorm's backward sums ``sum(g), sum(g*z)``, ``g = dx*mask``, into
+    the zeroed ``slab`` (:func:`new_slab`), so :func:`bn_backward` can run with ``presummed=True`` (no reduce pass)."""
     lib = _lib.require()
     _chk_act(dy, "conv2d_dgrad")
     dy = nhwc(dy)
@@ -120,9 +128,19 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
             raise ValueError("conv2d_dgrad: addend_mask needs an addend")
         if addend_mask.dtype != torch.uint8 or addend_mask.numel() != N * H * W * Cc // 8 or not addend_mask.is_contiguous():
             raise ValueError("conv2d_dgrad: addend_mask must be the contiguous uint8 [N*H*W, C/8] mask of bn_apply")
-    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, None, ptr(addend), ptr(addend_mask), int(addend_step), N, H, W,
-                             P, Q,
-                             K, Cc, R, S, stride, pad, 0, stream_ptr()), "conv2d_dgrad")
+    bz = bm = bslab = None
+    if bn_sums is not None:
+        bz, bm, bslab = bn_sums
+        bz = nhwc(bz)
+        if tuple(bz.shape) != tuple(dx.shape) or bz.dtype != BF16:
+            raise ValueError("conv2d_dgrad: bn_sums z must be bf16 with the shape of dx")
+        if bm is not None and (bm.dtype != torch.uint8 or bm.numel() != N * H * W * Cc // 8 or not bm.is_contiguous()):
+            raise ValueError("conv2d_dgrad: bn_sums mask must be the contiguous uint8 [N*H*W, C/8] mask of bn_apply")
+        if not dgrad_bn_sums_ok(dy, w_crsk, stride, R, S):
+            raise ValueError("conv2d_dgrad: bn_sums not available for this problem (see dgrad_bn_sums_ok)")
+    check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, ptr(bslab), ptr(addend), ptr(addend_mask),
+                             int(addend_step), ptr(bz), ptr(bm), N, H, W, P, Q, K, Cc, R, S, stride, pad, 0,
+                             stream_ptr()), "conv2d_dgrad")
     return dx
 
 
@@ -202,8 +220,10 @@ def bn_apply(x, scale, shift, residual=None, relu=True, want_mask=False, res_sca
     return (y, mask) if want_mask else y
 
 
-def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, slab=None, grad_out=None):
-    """Returns ``(dx, dres or None, dgamma, dbeta)``; ``mask`` is the bit mask from :func:`bn_apply` (``relu`` only)."""
+def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, slab=None, grad_out=None,
+                presummed=False):
+    """Returns ``(dx, dres or None, dgamma, dbeta)``; ``mask`` is the bit mask from :func:`bn_apply` (``relu`` only).
+    ``presummed``: ``slab`` already holds this BN's backward sums (left there by ``conv2d_dgrad(bn_sums=...)``)."""
     lib = _lib.require()
     _chk_act(dy, "bn_backward")
     dy, x = nhwc(dy), nhwc(x)
@@ -221,11 +241,13 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
     else:
         dgb = torch.empty((2, Cc), dtype=torch.float32, device=x.device)
     if slab is None:
+        if presummed:
+            raise ValueError("bn_backward: presummed needs the slab the sums were accumulated into")
         slab = new_slab(Cc, x.device)
     coef = slab.data_ptr() + _lib.bn_slots() * 2 * Cc * 4        # the slab's scratch rows
     check(lib.ddl_bn_backward(ptr(dy), ptr(mask) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
-                              int(grad_out is not None), stream_ptr()), "bn_backward")
+                              int(grad_out is not None), int(presummed), stream_ptr()), "bn_backward")
     return dx, dres, dgb[0], dgb[1]
 
 

