@@ -51,7 +51,8 @@ class Config:
     resume: Optional[str] = None
     jsonl: Optional[str] = None
     global_metrics: bool = False       # all-reduce metrics over ranks (reference reports rank 0's shard)
-    graph: bool = False                # replay the train step as one captured hipGraph (1 process, GPU, sequential)
+    graph: Optional[bool] = None       # hipGraph replay of the train step: True / False / None = auto (on for the
+                                       # launch-bound workloads: cnn, lstm, mlp, lenet5, resnet18_cifar; 1 process, GPU)
     check_replicas: int = 0            # every k steps compare parameter checksums across ranks (debug)
     max_steps: Optional[int] = None    # stop each epoch early (smoke tests)
     master_addr: str = "127.0.0.1"
@@ -107,7 +108,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--resume", default=None)
     p.add_argument("--jsonl", default=None)
     p.add_argument("--global-metrics", dest="global_metrics", action="store_true")
-    p.add_argument("--graph", action="store_true", help="capture the training step into a hipGraph")
+    p.add_argument("--graph", nargs="?", const="on", default="auto", choices=["on", "off", "auto"],
+                   help="replay the training step as one captured hipGraph (auto: on for the small, launch-bound workloads)")
     p.add_argument("--check-replicas", dest="check_replicas", type=int, default=0)
     p.add_argument("--max-steps", dest="max_steps", type=int, default=None)
     p.add_argument("--master-addr", dest="master_addr", default="127.0.0.1")
@@ -117,4 +119,5 @@ def build_parser() -> argparse.ArgumentParser:
 
 def parse_args(argv: Optional[List[str]] = None) -> Config:
     ns = build_parser().parse_args(argv)
+    ns.graph = {"on": True, "off": False, "auto": None}[ns.graph]
     return Config(**vars(ns)).validate()

@@ -70,6 +70,12 @@ class _L1(tnn.Module):
         return torch.nn.functional.l1_loss(out.float(), target.float())
 
 
+# Workloads whose step is launch-bound (hundreds of microsecond-kernels): with ``--graph auto`` (the default) a
+# single-process GPU run replays them from one captured hipGraph (2.7x-5.4x the eager step at batch 32,
+# profiles/r1_reference_workloads_vs_stock.txt).  Everything else runs eagerly unless ``--graph on``.
+_GRAPH_AUTO_MODELS = frozenset({"cnn", "densenet_ref", "lstm", "lstm_ref", "mlp", "mlp_ref", "lenet5", "resnet18_cifar"})
+
+
 class Trainer:
     def __init__(self, cfg: Config, info: Optional[ddist.RankInfo] = None, verbose: Optional[bool] = None,
                  printer=print):
@@ -196,7 +202,8 @@ class Trainer:
     def _graph_step(self, x, y):
         """The captured-graph path (``--graph``): single process, one device, fixed batch shape."""
         cfg = self.cfg
-        ok = (cfg.graph and self.info.world == 1 and cfg.mode in ("sequential", "data") and x.is_cuda
+        want = cfg.graph if cfg.graph is not None else cfg.model in _GRAPH_AUTO_MODELS
+        ok = (want and self.info.world == 1 and cfg.mode in ("sequential", "data") and x.is_cuda
               and len(self.optimizers) == 1 and hasattr(self.criterion, "last_correct"))
         if not ok:
             return None
