@@ -505,7 +505,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const bf16_t* __rest
   }
 }
 
+// Row 0 of a reduction slab -> out[c] (+)= sum over slots; the slab is left zero (both rows).
+__global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slab, int nslots, int C, float* __restrict__ out,
+                                                        int accumulate) {
+  float s1, s2;
+  slab_fold(slab, nslots, C, s1, s2);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x >= 64 || c >= C) return;
+  if (accumulate) out[c] += s1; else out[c] = s1;
+}
+
 // ================================================================ C ABI
+extern "C" int ddl_slab_fold(float* slab, int C, float* out, int accumulate, void* stream) {
+  if (C <= 0 || slab == nullptr || out == nullptr) return -1;
+  hipLaunchKernelGGL(slab_fold_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, BN_SLOTS, C, out,
+                     accumulate);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ddl_bn_slots() { return BN_SLOTS; }
 
 // slab: [BN_SLOTS][2][C] fp32 workspace, must be ZERO on entry (finalize re-zeroes it: self-cleaning).

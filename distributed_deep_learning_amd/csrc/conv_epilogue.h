@@ -93,9 +93,10 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
         for (int q = 0; q < 8; ++q) f[q] += a[q];
         vo = pack8(f);
       }
-      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
       if ((EPI & 2) && MODE == 1) {
-        // BN-backward sums for the BatchNorm behind this gradient: g = (stored, bf16-rounded) dx behind the ReLU mask
+        // Sums for the layer behind this gradient: g = (bf16-rounded) dx behind its ReLU gate; sum(g), sum(g*z).
+        // BatchNorm consumer: gate = bit mask, z = BN input.  conv+bias+ReLU consumer (bn_flags): gate = (z > 0) with
+        // z the ReLU output, and the GATED gradient is what gets stored.
         float g[8], z[8];
         unpack8(vo, g);
         const u32x4 zv = *reinterpret_cast<const u32x4*>(p.bnz + opix * (size_t)p.OC + (size_t)ncol);
@@ -104,10 +105,16 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
           const unsigned mk = p.bnz_mask[opix * (size_t)(p.OC >> 3) + (size_t)(ncol >> 3)];
 #pragma unroll
           for (int q = 0; q < 8; ++q) g[q] = ((mk >> q) & 1u) ? g[q] : 0.f;
+        } else if (p.bn_flags & 1) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g[q] = z[q] > 0.f ? g[q] : 0.f;
         }
+        if (p.bn_flags & 2) vo = pack8(g);
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * z[q]; }
-      } else if (EPI & 2) {
+      }
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
+      if ((EPI & 2) && MODE != 1) {
         float f[8];
         unpack8(v, f);
 #pragma unroll

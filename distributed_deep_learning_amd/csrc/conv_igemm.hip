@@ -317,7 +317,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
 
 extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
                               const void* addend, const void* addend_mask, int addend_step, const void* bnz,
-                              const void* bnz_mask, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                              const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
                               int pad, int relu, void* stream) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
@@ -334,7 +334,8 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   if (mode == 0 && addend != nullptr && stats != nullptr) return -5;   // forward statistics: of the raw conv output
   if (mode == 0 && (bnz != nullptr || bnz_mask != nullptr)) return -10;
   if (mode == 1 && ((stats != nullptr) != (bnz != nullptr) || (bnz_mask != nullptr && bnz == nullptr))) return -10;
-  p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask;
+  if (bn_flags < 0 || bn_flags > 3 || (bn_flags != 0 && (bnz == nullptr || bnz_mask != nullptr))) return -10;
+  p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask; p.bn_flags = bn_flags;
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;

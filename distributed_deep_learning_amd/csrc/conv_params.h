@@ -28,6 +28,9 @@ struct ConvParams {
   // The epilogue adds  sum(g), sum(g * z)  with  g = out * mask  into the stats slab.
   const bf16_t* bnz;
   const unsigned char* bnz_mask;
+  // bn_flags bit 0: no mask tensor, the gate is (bnz > 0) (dx is the gradient of a ReLU OUTPUT bnz: conv+bias+ReLU
+  // chains); bit 1: store the gated gradient (the consumer then needs no ReLU-backward pass; sum(g) = its bias grad)
+  int bn_flags;
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 

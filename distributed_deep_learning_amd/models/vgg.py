@@ -10,7 +10,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
-from ..nn.modules import conv_bn_act, to_device_input
+from ..nn.modules import conv_bn_act, conv_relu_chain, to_device_input
 
 CFG_D = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
 CFG_A = [64, "M", 128, "M", 256, 256, "M", 512, 512, "M", 512, 512, "M"]
@@ -52,6 +52,14 @@ class VGG(tnn.Module):
 
     def _features(self, x, lo=0, hi=None):
         mods = list(self.features)[lo:hi]
+        if not self.batch_norm:
+            # conv+bias+ReLU(+pool) runs are one fused node: ReLU gating and bias gradients ride in the next dgrad
+            units, i = [], 0
+            while i < len(mods):
+                pool = mods[i + 2] if i + 2 < len(mods) and isinstance(mods[i + 2], tnn.MaxPool2d) else None
+                units.append((mods[i], pool))
+                i += 3 if pool is not None else 2
+            return conv_relu_chain(units, x)
         i = 0
         while i < len(mods):
             m = mods[i]

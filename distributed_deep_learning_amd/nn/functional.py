@@ -353,6 +353,83 @@ class ConvBiasAct(torch.autograd.Function):
         return (dx, dw, db) + (None,) * 7
 
 
+_RELU_GATE = os.environ.get("DDL_DGRAD_RELU_GATE", "1") != "0"
+
+
+class ConvReluChain(torch.autograd.Function):
+    """A run of ``conv + bias + ReLU (+ max-pool)`` units (VGG's feature extractor) as ONE autograd node.
+
+    Owning the run's backward removes the ReLU-backward / bias-gradient pass (read dy, read y, write dx) of every unit
+    but the last: unit ``i``'s dgrad differentiates ``a = relu(conv_{i-1} + b)`` (or its max-pool), which is its own
+    input, so its epilogue stores ``dx * (a > 0)`` and sums it per channel — the gated gradient and the bias gradient
+    of unit ``i-1`` — while the tile is on chip.  Gating the POOLED gradient is equivalent: a pooled value is > 0 iff
+    its arg-max element is, and that is where max-pool backward routes the gradient.
+    ``specs``: tuple of ``(conv_module, (k, stride, pad) or None)``; parameters follow as ``w0, b0, w1, b1, ...``.
+    """
+
+    @staticmethod
+    def forward(ctx, x, specs, *params):
+        h = K.nhwc(_bf16(x))
+        saved = []
+        for conv, pool in specs:
+            krsc, crsk = conv.packed()
+            y, _ = K.conv2d_fwd(h, krsc, conv.stride[0], conv.padding[0], bias=conv.bias, relu=True)
+            idx = None
+            nxt = y
+            if pool is not None:
+                nxt, idx = K.maxpool_fwd(y, *pool)
+            saved.extend([h, y, crsk, idx])
+            h = nxt
+        ctx.save_for_backward(*saved)
+        ctx.specs = specs
+        return h
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved, specs = ctx.saved_tensors, ctx.specs
+        n = len(specs)
+        d = K.nhwc(_bf16(dout))
+        grads = [None] * (2 * n)
+        gated = False                       # d already carries this unit's ReLU gate, bias gradient already taken
+        for i in range(n - 1, -1, -1):
+            conv, pool = specs[i]
+            x_in, y, crsk, idx = saved[4 * i:4 * i + 4]
+            if pool is not None:
+                d = K.maxpool_bwd(d, idx, tuple(y.shape[2:]), *pool)
+            bias = conv.bias
+            if not gated:
+                arena = getattr(bias, "_ddl_arena", None)
+                if arena is not None and arena.grad_is_arena_view(bias):
+                    d, _ = K.relu_bwd_bias_grad(d, y, grad_out=bias.grad)
+                    arena.notify_grad_ready(bias)
+                else:
+                    d, grads[2 * i + 1] = K.relu_bwd_bias_grad(d, y)
+            R, S = conv.kernel_size
+            stride, pad = conv.stride[0], conv.padding[0]
+            dx = None
+            gated = False
+            if i > 0 or ctx.needs_input_grad[0]:
+                if i > 0 and _RELU_GATE and K.dgrad_bn_sums_ok(d, crsk, stride, R, S):
+                    pconv = specs[i - 1][0]
+                    slab = getattr(conv, "_gate_slab", None)
+                    if slab is None or slab.device != d.device:
+                        slab = conv._gate_slab = K.new_slab(x_in.shape[1], d.device)
+                    dx = K.conv2d_dgrad(d, crsk, tuple(x_in.shape[2:]), stride, pad, relu_gate=(x_in, slab))
+                    pb = pconv.bias
+                    arena = getattr(pb, "_ddl_arena", None)
+                    if arena is not None and arena.grad_is_arena_view(pb):
+                        K.slab_fold(slab, pb.grad, accumulate=True)
+                        arena.notify_grad_ready(pb)
+                    else:
+                        grads[2 * (i - 1) + 1] = K.slab_fold(slab, torch.empty_like(pb, dtype=torch.float32))
+                    gated = True
+                else:
+                    dx = K.conv2d_dgrad(d, crsk, tuple(x_in.shape[2:]), stride, pad)
+            grads[2 * i] = _wgrad(conv.weight, d, x_in, R, S, stride, pad, conv.in_channels)
+            d = dx
+        return (d, None, *grads)
+
+
 class BNAct(torch.autograd.Function):
     """Stand-alone training BatchNorm (+ residual)(+ ReLU) for inputs not produced by our conv (e.g. concat)."""
 

@@ -240,6 +240,34 @@ def conv_bn_relu_pool(conv: Conv2d, bn: BatchNorm2d, pool, x):
     return pool(conv_bn_act(conv, bn, x, relu=True))
 
 
+def conv_relu_chain(units, x):
+    """Run ``units`` = ``[(Conv2d, MaxPool2d or None), ...]`` (conv + bias + ReLU, optionally followed by a max-pool)
+    as one fused autograd node on the GPU (:class:`functional.ConvReluChain`); layer by layer elsewhere."""
+    def pool_geom(p):
+        k, s, pd = p.kernel_size, p.stride, p.padding
+        ok = (isinstance(p, tnn.MaxPool2d) and all(isinstance(v, int) for v in (k, s, pd)) and p.dilation == 1
+              and not p.ceil_mode and not p.return_indices)
+        return (k, s, pd) if ok else None
+
+    geoms = [None if p is None else pool_geom(p) for _, p in units]
+    fused = (x.is_cuda and torch.is_grad_enabled() and len(units) >= 2
+             and all(c.bias is not None and c._native_ok() and c.out_channels % 8 == 0 for c, _ in units)
+             and all(c.in_channels % 8 == 0 for c, _ in units[1:])
+             and all(g is not None for (_, p), g in zip(units, geoms) if p is not None))
+    if fused:
+        if x.shape[1] != _pad8(units[0][0].in_channels):
+            x = to_device_input(x)
+        params = []
+        for c, _ in units:
+            params += [c.weight, c.bias]
+        return F.ConvReluChain.apply(x, tuple((c, g) for (c, _), g in zip(units, geoms)), *params)
+    for c, p in units:
+        x = c(x, relu=True)
+        if p is not None:
+            x = p(x)
+    return x
+
+
 def residual_block(units, ds, x):
     """Run a residual block — ``units``: main-path (conv, bn) pairs, ``ds``: optional projection (conv, bn) — as one
     fused autograd node on the GPU (see :class:`functional.ResidualBlock`); layer-by-layer elsewhere."""

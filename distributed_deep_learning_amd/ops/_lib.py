@@ -23,11 +23,12 @@ _load_error: Exception | None = None
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 _SIGS = {
-    "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 12 + [_vp],
+    "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 13 + [_vp],
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_spin": [_ll, _vp],
     "ddl_bn_slots": [],
+    "ddl_slab_fold": [_vp, _i, _vp, _i, _vp],
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
     "ddl_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -80,7 +80,7 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
     if bias is not None and (bias.dtype != torch.float32 or bias.numel() != K):
         raise TypeError("conv2d_fwd: bias must be fp32 [K]")
-    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, 1, None, None,
+    check(lib.ddl_conv_igemm(0, ptr(x), ptr(w_krsc), ptr(y), ptr(bias), ptr(stats), None, None, 1, None, None, 0,
                              N, P, Q, H, W, Cc, K, R, S, stride, pad, int(relu), stream_ptr()), "conv2d_fwd")
     return y, stats
 
@@ -91,7 +91,8 @@ def dgrad_bn_sums_ok(dy, w_crsk, stride, R, S) -> bool:
     return dy.numel() * 2 < 0xFFFF0000 and w_crsk.numel() * 2 < 0xFFFF0000 and (stride == 1 or (R >= stride and S >= stride))
 
 
-def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None, addend_step=1, bn_sums=None):
+def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=None, addend_step=1, bn_sums=None,
+                 relu_gate=None):
     """dy: bf16 NHWC ``[N,K,P,Q]``; w_crsk: bf16 ``[C,R,S,K]``; returns dx ``[N,C,H,W]`` (bf16 NHWC).
     ``addend`` (bf16, shape of dx) is added in the epilogue: gradient accumulation of a second path for free.
     ``addend_mask`` (uint8 ``[N*H*W, C/8]``, the ReLU bit mask :func:`bn_apply` writes) zeroes the addend where its
@@ -101,7 +102,10 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
     which is zero everywhere else, without the zero-filled full-size tensor.
     ``bn_sums = (z, mask or None, slab)``: dx is the gradient of ``act(BN(z))`` (``z`` bf16, shape of dx; ``mask`` its
     ReLU bit mask); the epilogue accumulates that BatchNorm's backward sums ``sum(g), sum(g*z)``, ``g = dx*mask``, into
-    the zeroed ``slab`` (:func:`new_slab`), so :func:`bn_backward` can run with ``presummed=True`` (no reduce pass)."""
+    the zeroed ``slab`` (:func:`new_slab`), so :func:`bn_backward` can run with ``presummed=True`` (no reduce pass).
+    ``relu_gate = (a, slab)``: dx is the gradient of a ReLU OUTPUT ``a`` (bf16, shape of dx — the conv's own input in a
+    conv+bias+ReLU chain).  The epilogue stores ``dx * (a > 0)`` — the producer needs no ReLU-backward pass — and leaves
+    its per-channel sums (= the producer's bias gradient) in row 0 of ``slab`` (:func:`slab_fold`)."""
     lib = _lib.require()
     _chk_act(dy, "conv2d_dgrad")
     dy = nhwc(dy)
@@ -129,6 +133,12 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
         if addend_mask.dtype != torch.uint8 or addend_mask.numel() != N * H * W * Cc // 8 or not addend_mask.is_contiguous():
             raise ValueError("conv2d_dgrad: addend_mask must be the contiguous uint8 [N*H*W, C/8] mask of bn_apply")
     bz = bm = bslab = None
+    flags = 0
+    if relu_gate is not None:
+        if bn_sums is not None:
+            raise ValueError("conv2d_dgrad: bn_sums and relu_gate are exclusive")
+        bn_sums = (relu_gate[0], None, relu_gate[1])
+        flags = 3
     if bn_sums is not None:
         bz, bm, bslab = bn_sums
         bz = nhwc(bz)
@@ -139,7 +149,7 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
         if not dgrad_bn_sums_ok(dy, w_crsk, stride, R, S):
             raise ValueError("conv2d_dgrad: bn_sums not available for this problem (see dgrad_bn_sums_ok)")
     check(lib.ddl_conv_igemm(1, ptr(dy), ptr(w_crsk), ptr(dx), None, ptr(bslab), ptr(addend), ptr(addend_mask),
-                             int(addend_step), ptr(bz), ptr(bm), N, H, W, P, Q, K, Cc, R, S, stride, pad, 0,
+                             int(addend_step), ptr(bz), ptr(bm), flags, N, H, W, P, Q, K, Cc, R, S, stride, pad, 0,
                              stream_ptr()), "conv2d_dgrad")
     return dx
 
@@ -249,6 +259,16 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
                               int(grad_out is not None), int(presummed), stream_ptr()), "bn_backward")
     return dx, dres, dgb[0], dgb[1]
+
+
+def slab_fold(slab, out, accumulate=False):
+    """``out[c] (+)= sum over slots of slab[:, 0, c]``; the slab is zero afterwards (ready for the next use)."""
+    lib = _lib.require()
+    Cc = slab.shape[-1]
+    if out.numel() != Cc or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("slab_fold: out must be a contiguous fp32 [C] tensor")
+    check(lib.ddl_slab_fold(ptr(slab), Cc, ptr(out), int(accumulate), stream_ptr()), "slab_fold")
+    return out
 
 
 def bn_backward_pair(dy, mask, xa, xb, stat_a, stat_b, relu=True, slabs=None, grad_outs=None):
