@@ -67,7 +67,7 @@ _PAIR_BN = os.environ.get("DDL_BN_PAIR", "1") != "0"
 # ResNet-50, B=512: 13.41k img/s with it vs 13.49-13.54k without - the extra epilogue work (z + mask reads, LDS
 # reduction, atomics) sits on the critical path of short 1x1 dgrads and costs more than the bandwidth-bound reduce
 # passes it removes.  Kept as an option.
-_DGRAD_BN_SUMS = os.environ.get("DDL_DGRAD_BN_SUMS", "0") != "0"
+_DGRAD_BN_SUMS = int(os.environ.get("DDL_DGRAD_BN_SUMS", "0"))       # 1: every in-block dgrad, 2: only 3x3 and larger
 
 
 def _bn_bwd_pair(dout, mask, saved, metas, ia, ib):
@@ -267,6 +267,8 @@ class ResidualBlock(torch.autograd.Function):
                 if not _DGRAD_BN_SUMS or prev < first_main:
                     return None
                 conv = metas[idx][0]
+                if _DGRAD_BN_SUMS == 2 and conv.kernel_size == (1, 1):
+                    return None
                 crsk = saved[5 * idx + 4]
                 if not K.dgrad_bn_sums_ok(saved[5 * idx + 1], crsk, conv.stride[0], *conv.kernel_size):
                     return None

@@ -325,11 +325,11 @@ def test_residual_block_with_dgrad_epilogue_bn_sums_matches_default():
     for flag in (False, True):
         torch.manual_seed(3)
         m = models.build("resnet50").to(_dev())
-        Fn._DGRAD_BN_SUMS = flag
+        Fn._DGRAD_BN_SUMS = int(flag)
         try:
             torch.nn.functional.cross_entropy(m(x).float(), y).backward()
         finally:
-            Fn._DGRAD_BN_SUMS = False
+            Fn._DGRAD_BN_SUMS = 0
         grads[flag] = {n: p.grad.float().clone() for n, p in m.named_parameters()}
     # 53 stacked BatchNorms over tiny per-channel samples amplify bf16 / summation-order differences towards the
     # input (run-to-run noise of the atomics alone is a few percent at the stem): bound the worst tensor loosely,
