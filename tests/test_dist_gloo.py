@@ -59,6 +59,35 @@ def test_bucketed_allreduce_equals_mean_of_rank_grads(bucket_mb):
     assert torch.allclose(out[0]["grad"], (grads[0] + grads[1]) / 2, atol=1e-7)
 
 
+@pytest.mark.parametrize("world,mode", [(4, "ps"), (8, "allreduce"), (8, "ps")])
+def test_reducer_at_the_benchmark_world_sizes(world, mode):
+    """The same bucket / shard arithmetic at the world sizes of the scaling benchmark (4, 8 ranks): synchronised
+    gradients equal the mean of the per-rank gradients, PS shards tile every bucket exactly."""
+    out = run_ranks(_grad_mean_worker, world, (mode, 1e-3))
+    from distributed_deep_learning_amd.parallel import ParamArena
+    m = _mlp(7)
+    arena = ParamArena(m.named_parameters(), bucket_bytes=int(1e-3 * 2**20), shard_multiple=world)
+    grads = []
+    for r in range(world):
+        arena.zero_grad()
+        x, y = _data(r)
+        ((m(x) - y) ** 2).mean().backward()
+        grads.append(arena.grad.clone())
+    mean = sum(grads) / world
+    assert out[0]["nb"] > 1
+    for r in range(world):
+        assert torch.equal(out[r]["w"], out[0]["w"])
+        if mode == "allreduce":
+            assert torch.allclose(out[r]["grad"], mean, atol=1e-6)
+        else:
+            for lo, hi in out[r]["ranges"]:
+                assert torch.allclose(out[r]["grad"][lo:hi], mean[lo:hi], atol=1e-6)
+    if mode == "ps":
+        covered = sorted(x for r in range(world) for x in out[r]["ranges"])
+        assert covered[0][0] == 0 and covered[-1][1] == arena.total
+        assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+
+
 def test_ps_mode_reduces_owned_shards():
     out = run_ranks(_grad_mean_worker, 2, ("ps", 1e-3))
     ref = run_ranks(_grad_mean_worker, 2, ("allreduce", 1e-3))
