@@ -55,6 +55,7 @@ class Config:
                                        # launch-bound workloads: cnn, lstm, mlp, lenet5, resnet18_cifar; 1 process, GPU)
     check_replicas: int = 0            # every k steps compare parameter checksums across ranks (debug)
     max_steps: Optional[int] = None    # stop each epoch early (smoke tests)
+    inject_fault: Optional[str] = None  # "RANK:STEP": that rank dies (hard exit) before that global step - fault drill
     master_addr: str = "127.0.0.1"
     master_port: int = 29500
 
@@ -112,6 +113,8 @@ def build_parser() -> argparse.ArgumentParser:
                    help="replay the training step as one captured hipGraph (auto: on for the small, launch-bound workloads)")
     p.add_argument("--check-replicas", dest="check_replicas", type=int, default=0)
     p.add_argument("--max-steps", dest="max_steps", type=int, default=None)
+    p.add_argument("--inject-fault", dest="inject_fault", default=None, metavar="RANK:STEP",
+                   help="fault drill: the given rank exits hard before the given global step")
     p.add_argument("--master-addr", dest="master_addr", default="127.0.0.1")
     p.add_argument("--master-port", dest="master_port", type=int, default=29500)
     return p

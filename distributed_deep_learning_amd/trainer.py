@@ -222,7 +222,20 @@ class Trainer:
         self.global_step += 1
         return loss, g.correct
 
+    def _maybe_die(self) -> None:
+        """Fault drill (``--inject-fault RANK:STEP``): simulate a killed rank.  The launcher must notice (spawn tears
+        the job down / the survivors' collectives time out) and the run must be resumable from the last checkpoint."""
+        spec = self.cfg.inject_fault
+        if spec:
+            r, st = (int(v) for v in spec.split(":"))
+            if r == self.info.rank and self.global_step + 1 == st:
+                import os
+                import sys
+                print(f"[fault drill] rank {r} exits before step {st}", file=sys.stderr, flush=True)
+                os._exit(17)
+
     def train_step(self, x, y):
+        self._maybe_die()
         out = self._graph_step(x, y)
         if out is not None:
             return out

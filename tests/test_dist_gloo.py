@@ -217,6 +217,27 @@ def test_external_launcher_env_is_honoured(tmp_path):
     assert sum(1 for l in r.stdout.splitlines() if l.startswith('"test ends at ')) == 1
 
 
+# --------------------------------------------------------------------------------------------- failure drill
+def test_killed_rank_fails_the_job_and_resume_continues(tmp_path):
+    """a rank that dies mid-epoch must fail the whole job promptly (no hang), and the job must continue
+    from the last checkpoint with ``--resume``."""
+    import time
+    ck = os.path.join(tmp_path, "ck.pt")
+    res = os.path.join(tmp_path, "hist.jsonl")
+    base = [sys.executable, "-m", "distributed_deep_learning_amd", "--model", "mlp", "-m", "data", "-r", "2", "-e", "3",
+            "-b", "16", "--samples", "256", "--checkpoint", ck]
+    t0 = time.time()
+    r = subprocess.run(base + ["--inject-fault", "1:9"], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0, "the job must not report success when a rank died"
+    assert "[fault drill] rank 1 exits before step 9" in r.stderr
+    assert time.time() - t0 < 200                                   # torn down, not waiting for a timeout
+    assert os.path.exists(ck), "epoch 1 finished before the fault: its checkpoint must exist"
+    r2 = subprocess.run(base + ["--resume", ck, "--jsonl", res], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    epochs = [json.loads(l)["epoch"] for l in open(res) if '"train_loss"' in l]
+    assert epochs and epochs[0] >= 2 and epochs[-1] == 3            # continued, did not start over
+
+
 # --------------------------------------------------------------------------------------------- debug ledger
 def _ledger_worker(rank, world):
     from distributed_deep_learning_amd.parallel import DistributedDataParallel, ParamArena
