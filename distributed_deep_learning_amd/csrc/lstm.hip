@@ -44,8 +44,15 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_fwd_kernel(
     float* __restrict__ cseq, bf16_t* __restrict__ gates, int B, int T, int save) {
   constexpr int NT = H / 16 * 64;
   constexpr int KH = H / 32, KI = I / 32;
-  constexpr int HP = H + 8;                         // LDS row pitch (elements): 16-byte skew per row
-  __shared__ __attribute__((aligned(16))) bf16_t hbuf[2][16][HP];
+  // h tile: 16 rows (batch) x H bf16, no padding; 16-byte chunks XOR-swizzled by the row so that the ds_read_b128
+  // fragment reads (row = lane & 15, chunk = 4*ks + lane/16 — the conv kernels' pattern) are bank-conflict free:
+  // 256-byte rows: chunk ^ row; 128-byte rows: chunk ^ ((row >> 1) & 7).  (PMC before: 50 % conflict cycles.)
+  constexpr int ROWB = H * 2;
+  __shared__ __attribute__((aligned(16))) char hbuf[2 * 16 * ROWB];
+  auto hoff = [](int buf, int row, int chunk) {
+    const int sw = (ROWB >= 256) ? row : ((row >> 1) & 7);
+    return (buf * 16 + row) * ROWB + ((chunk ^ sw) << 4);
+  };
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q4 = lane >> 4;
@@ -74,7 +81,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_fwd_kernel(
   for (int idx = tid; idx < 16 * (H / 8); idx += NT) {
     const int r = idx / (H / 8), ch = idx % (H / 8);
     const size_t br = (size_t)((b0 + r < B) ? b0 + r : B - 1);
-    *reinterpret_cast<u32x4*>(&hbuf[0][r][ch * 8]) =
+    *reinterpret_cast<u32x4*>(hbuf + hoff(0, r, ch)) =
         *reinterpret_cast<const u32x4*>(hseq + br * (size_t)(T + 1) * H + ch * 8);
   }
   float c[4];
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_fwd_kernel(
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ih[g][ks], xc[ks], acc[g], 0, 0, 0);
 #pragma unroll
     for (int ks = 0; ks < KH; ++ks) {
-      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(&hbuf[cur][n][ks * 32 + 8 * q4]);
+      const bf16x8 hf = *reinterpret_cast<const bf16x8*>(hbuf + hoff(cur, n, ks * 4 + q4));
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         acc[g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_hh[g][ks], hf, acc[g], 0, 0, 0);
@@ -123,7 +130,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_fwd_kernel(
       h[i] = go[i] * tanh_f(c[i]);
     }
     const u32x2 hp = pack4(h);
-    *reinterpret_cast<u32x2*>(&hbuf[cur ^ 1][n][u0]) = hp;
+    *reinterpret_cast<u32x2*>(hbuf + hoff(cur ^ 1, n, 2 * w + (q4 >> 1)) + (q4 & 1) * 8) = hp;
     if (live) {
       *reinterpret_cast<u32x2*>(hseq + ((size_t)b * (T + 1) + t + 1) * H + u0) = hp;
       if (save) {
@@ -154,8 +161,10 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
     float* __restrict__ dh0, float* __restrict__ dc0, int B, int T) {
   constexpr int G4 = 4 * H;
   constexpr int KS = G4 / 32;
-  constexpr int GP = G4 + 8;
-  __shared__ __attribute__((aligned(16))) bf16_t dgbuf[2][16][GP];
+  // gate-gradient tile: 16 rows x 4H bf16 (rows are multiples of 256 bytes), chunk ^ row swizzle as in the forward
+  constexpr int ROWB = G4 * 2;
+  __shared__ __attribute__((aligned(16))) char dgbuf[2 * 16 * ROWB];
+  auto goff = [](int buf, int row, int chunk) { return (buf * 16 + row) * ROWB + ((chunk ^ row) << 4); };
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int n = lane & 15, q4 = lane >> 4;
@@ -204,11 +213,14 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
       dc[i] = dct * gf[i];
     }
     const u32x2 pi = pack4(dai), pf = pack4(daf), pg = pack4(dag), po = pack4(dao);
-    bf16_t* lp = &dgbuf[cur][n][u0];
-    *reinterpret_cast<u32x2*>(lp) = pi;
-    *reinterpret_cast<u32x2*>(lp + H) = pf;
-    *reinterpret_cast<u32x2*>(lp + 2 * H) = pg;
-    *reinterpret_cast<u32x2*>(lp + 3 * H) = po;
+    {
+      constexpr int GC = H / 8;                       // chunks per gate
+      const int c0 = 2 * w + (q4 >> 1), bo = (q4 & 1) * 8;
+      *reinterpret_cast<u32x2*>(dgbuf + goff(cur, n, c0) + bo) = pi;
+      *reinterpret_cast<u32x2*>(dgbuf + goff(cur, n, GC + c0) + bo) = pf;
+      *reinterpret_cast<u32x2*>(dgbuf + goff(cur, n, 2 * GC + c0) + bo) = pg;
+      *reinterpret_cast<u32x2*>(dgbuf + goff(cur, n, 3 * GC + c0) + bo) = po;
+    }
     if (live) {
       bf16_t* gp = dG + ((size_t)b * T + t) * G4 + u0;
       *reinterpret_cast<u32x2*>(gp) = pi;
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&dgbuf[cur][n][ks * 32 + 8 * q4]);
+      const bf16x8 bf = *reinterpret_cast<const bf16x8*>(dgbuf + goff(cur, n, ks * 4 + q4));
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[ks], bf, acc, 0, 0, 0);
     }
 #pragma unroll
