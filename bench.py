@@ -41,6 +41,8 @@ def main() -> int:
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire format of the gradient collectives (fp32 = in place on the arena, the default)")
+    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
+                    help="collectives through torch.distributed (default) or the native RCCL communicator (csrc/comm.cpp)")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: issue the (identity) RCCL collectives of the DP reducer even on one GPU")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
@@ -74,7 +76,7 @@ def main() -> int:
     ddp = None
     if info.world > 1 or a.force_collectives:
         ddp = DistributedDataParallel(model, bucket_mb=a.bucket_mb, mode=a.sync, force_collectives=a.force_collectives,
-                                      grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else None)
+                                      grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else None, comm=a.comm)
         arena = ddp.arena
     else:
         arena = ParamArena(model.named_parameters(), bucket_bytes=int(a.bucket_mb * 2**20))
@@ -137,7 +139,7 @@ def main() -> int:
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random N(0,1) images, random-init weights)",
             "config": {"model": a.model, "global_batch": gb, "per_gpu_batch": a.batch, "image": image, "seq_len": None,
                        "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
-                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "hip_graph": a.graph == "on" and info.world == 1},
+                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": a.comm, "hip_graph": a.graph == "on" and info.world == 1},
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S[a.batch], 3)
                                              if a.model == "resnet50" and a.batch in STOCK_PYTORCH_1GPU_IMG_S else None,
             "final_loss": round(final_loss, 4),

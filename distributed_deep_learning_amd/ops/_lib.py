@@ -58,6 +58,15 @@ _SIGS = {
     "ddl_flat_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_flat_sgd": [_vp] * 9 + [_i, _i, _i, _vp],
     "ddl_flat_adam": [_vp] * 8 + [_i, _i, _i, _vp],
+    "ddl_comm_load": [C.c_char_p],
+    "ddl_comm_version": [],
+    "ddl_comm_unique_id": [_vp],
+    "ddl_comm_init": [_vp, _i, _i, _vp],
+    "ddl_comm_destroy": [_vp],
+    "ddl_comm_all_reduce": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "ddl_comm_reduce_scatter": [_vp, _vp, _vp, _ll, _i, _i, _vp],
+    "ddl_comm_all_gather": [_vp, _vp, _vp, _ll, _i, _vp],
+    "ddl_comm_broadcast": [_vp, _vp, _ll, _i, _i, _vp],
     "ddl_lstm_supported": [_i, _i],
     "ddl_lstm_fwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ddl_lstm_bwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

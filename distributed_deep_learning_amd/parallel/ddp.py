@@ -37,12 +37,15 @@ class DistributedDataParallel(tnn.Module):
     def __init__(self, module: tnn.Module, bucket_mb: float = 32.0, mode: str = "allreduce",
                  arena: Optional[ParamArena] = None, process_group=None, broadcast_buffers: bool = True,
                  first_bucket_mb: Optional[float] = None, force_collectives: bool = False,
-                 grad_dtype: Optional[torch.dtype] = None):
+                 grad_dtype: Optional[torch.dtype] = None, comm: str = "torch"):
         """``force_collectives``: issue the (identity) collectives even with a world size of 1 — lets a one-GPU box
         drive the real RCCL path (async works, comm-stream ordering, reduce-scatter / all-gather shapes).
         ``grad_dtype=torch.bfloat16``: gradients travel in bf16 (each bucket is packed into a persistent bf16 buffer,
         reduced, unpacked into the fp32 arena) — half the xGMI bytes for bandwidth-bound models such as VGG-16
-        (553 MB of fp32 gradients per step); the default reduces the fp32 arena in place, with no copies."""
+        (553 MB of fp32 gradients per step); the default reduces the fp32 arena in place, with no copies.
+        ``comm="native"``: gradient / parameter collectives go through :class:`.native_comm.NativeCommunicator` (direct
+        RCCL calls from ``csrc/comm.cpp`` on its own stream) instead of ``torch.distributed``, which then only
+        bootstraps (unique-id exchange, initial broadcast).  GPU only."""
         super().__init__()
         if mode not in ("allreduce", "ps"):
             raise ValueError("mode must be 'allreduce' or 'ps'")
@@ -65,6 +68,14 @@ class DistributedDataParallel(tnn.Module):
             raise ValueError("grad_dtype must be None / torch.float32 (in place) or torch.bfloat16")
         self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None
         self._comm_bufs: dict = {}
+        if comm not in ("torch", "native"):
+            raise ValueError("comm must be 'torch' or 'native'")
+        self.ncomm = None
+        if comm == "native" and self.dist:
+            if arena.device.type != "cuda":
+                raise ValueError("comm='native' drives RCCL directly: GPU tensors only")
+            from .native_comm import NativeCommunicator
+            self.ncomm = NativeCommunicator(self.rank, self.world, arena.device, group=self.pg)
         self.broadcast_buffers = broadcast_buffers
         self._handles: List = []
         self._pending = [0] * len(arena.buckets)
@@ -155,13 +166,19 @@ class DistributedDataParallel(tnn.Module):
             src = self._comm_buf(("bucket", b), g.numel())
             src.copy_(g)                                             # pack: fp32 arena -> bf16 wire format
         if self.mode == "allreduce":
-            h = td.all_reduce(src, op=td.ReduceOp.AVG if nccl else td.ReduceOp.SUM, group=self.pg, async_op=True)
+            if self.ncomm is not None:
+                h = self.ncomm.all_reduce(src, average=True)
+            else:
+                h = td.all_reduce(src, op=td.ReduceOp.AVG if nccl else td.ReduceOp.SUM, group=self.pg, async_op=True)
             dst, part = g, src
         else:
             lo, hi = self.arena.shard_range(b, self.rank, self.world)
             dst = self.arena.grad[lo:hi]
             off = lo - self.arena.buckets[b].lo
-            if nccl:
+            if self.ncomm is not None:
+                part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
+                h = self.ncomm.reduce_scatter(part, src, average=True)
+            elif nccl:
                 part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
                 h = td.reduce_scatter_tensor(part, src, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
             else:   # gloo has no reduce-scatter: same semantics via all-reduce, only the owned shard is used
@@ -210,7 +227,9 @@ class DistributedDataParallel(tnn.Module):
             full = a.bucket_master(b)
             lo, hi = a.shard_range(b, self.rank, self.world)
             own = a.master[lo:hi]
-            if self.backend == "nccl":
+            if self.ncomm is not None:
+                handles.append(self.ncomm.all_gather(full, own))
+            elif self.backend == "nccl":
                 handles.append(td.all_gather_into_tensor(full, own, group=self.pg, async_op=True))
             else:
                 n = hi - lo

@@ -1,0 +1,137 @@
+"""Native RCCL communicator (``csrc/comm.cpp``): collectives issued straight from this library on a HIP stream the
+communicator owns, next to — not through — ``torch.distributed``.
+
+Why: one ctypes call per collective instead of a c10d work object, a communication stream whose ordering against
+the compute streams is explicit (events), and calls that are plain stream operations (capturable in a hipGraph).
+``torch.distributed`` stays the bootstrap: the 128-byte RCCL unique id travels through the default process group
+(any backend) or a ``TCPStore``.  RCCL itself is the copy torch ships (``torch/lib/librccl.so``), resolved with
+``dlopen`` so the process never maps two RCCLs.
+
+Opt-in (``DistributedDataParallel(comm="native")`` / ``--comm native``): this box can only exercise it with one
+rank (identity collectives), the multi-rank path of record is ``torch.distributed``.
+
+Reference behaviour replaced: blocking per-parameter ``all_reduce`` through c10d
+(``/root/reference/src/pytorch/CNN/main.py:134-140``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+from ..ops import _lib
+from ..ops._lib import check
+
+_DT = {torch.float32: 0, torch.bfloat16: 1}
+
+
+def _rccl_path() -> Optional[bytes]:
+    p = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return p.encode() if os.path.exists(p) else None
+
+
+class _Handle:
+    """Completion of one collective: ``wait()`` orders the CURRENT stream behind it (no host blocking)."""
+
+    __slots__ = ("event",)
+
+    def __init__(self, event: torch.cuda.Event):
+        self.event = event
+
+    def wait(self) -> None:
+        torch.cuda.current_stream().wait_event(self.event)
+
+
+class NativeCommunicator:
+    def __init__(self, rank: int, world: int, device: torch.device, group=None, store=None):
+        """Collective constructor (every rank calls it).  The unique id is broadcast through ``group`` (a
+        ``torch.distributed`` group, default: the default group when initialised) or exchanged through ``store``
+        (anything with ``set`` / ``get``, e.g. ``torch.distributed.TCPStore``); a single rank needs neither."""
+        self.lib = _lib.require()
+        check(self.lib.ddl_comm_load(_rccl_path()), "ddl_comm_load (RCCL not found)")
+        self.rank, self.world, self.device = rank, world, device
+        torch.cuda.set_device(device)
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            check(self.lib.ddl_comm_unique_id(C.addressof(ident)), "ncclGetUniqueId")
+        if world > 1:
+            import torch.distributed as td
+            if store is not None:
+                if rank == 0:
+                    store.set("ddl_rccl_id", bytes(ident))
+                else:
+                    C.memmove(ident, store.get("ddl_rccl_id"), 128)
+            elif td.is_available() and td.is_initialized():
+                t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone()
+                dev_t = t.to(device) if td.get_backend(group) == "nccl" else t
+                td.broadcast(dev_t, 0, group=group)
+                C.memmove(ident, bytes(dev_t.cpu().numpy().tobytes()), 128)
+            else:
+                raise RuntimeError("NativeCommunicator: world > 1 needs a process group or a store for the unique id")
+        comm = C.c_void_p()
+        check(self.lib.ddl_comm_init(C.addressof(ident), rank, world, C.byref(comm)), "ncclCommInitRank")
+        self._comm = comm
+        self.stream = torch.cuda.Stream(device=device)
+
+    @property
+    def version(self) -> int:
+        return self.lib.ddl_comm_version()
+
+    # ------------------------------------------------------------------ plumbing
+    def _enter(self) -> int:
+        """Order the comm stream behind everything enqueued on the current stream; returns its raw handle."""
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return self.stream.cuda_stream
+
+    def _done(self) -> _Handle:
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return _Handle(ev)
+
+    @staticmethod
+    def _dt(t: torch.Tensor) -> int:
+        if t.dtype not in _DT or not t.is_cuda or not t.is_contiguous():
+            raise TypeError("native collectives take contiguous fp32 / bf16 GPU tensors")
+        return _DT[t.dtype]
+
+    # ------------------------------------------------------------------ collectives (asynchronous)
+    def all_reduce(self, t: torch.Tensor, average: bool = True) -> _Handle:
+        st = self._enter()
+        check(self.lib.ddl_comm_all_reduce(self._comm, t.data_ptr(), t.data_ptr(), t.numel(), self._dt(t), int(average),
+                                           st), "ncclAllReduce")
+        return self._done()
+
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, average: bool = True) -> _Handle:
+        if inp.numel() != out.numel() * self.world or inp.dtype != out.dtype:
+            raise ValueError("reduce_scatter: input must hold world x output elements of the same dtype")
+        st = self._enter()
+        check(self.lib.ddl_comm_reduce_scatter(self._comm, inp.data_ptr(), out.data_ptr(), out.numel(), self._dt(out),
+                                               int(average), st), "ncclReduceScatter")
+        return self._done()
+
+    def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> _Handle:
+        if out.numel() != inp.numel() * self.world or inp.dtype != out.dtype:
+            raise ValueError("all_gather: output must hold world x input elements of the same dtype")
+        st = self._enter()
+        check(self.lib.ddl_comm_all_gather(self._comm, inp.data_ptr(), out.data_ptr(), inp.numel(), self._dt(inp), st),
+              "ncclAllGather")
+        return self._done()
+
+    def broadcast(self, t: torch.Tensor, root: int = 0) -> _Handle:
+        st = self._enter()
+        check(self.lib.ddl_comm_broadcast(self._comm, t.data_ptr(), t.numel(), self._dt(t), root, st), "ncclBroadcast")
+        return self._done()
+
+    def close(self) -> None:
+        if getattr(self, "_comm", None):
+            self.stream.synchronize()
+            self.lib.ddl_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass

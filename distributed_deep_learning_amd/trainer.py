@@ -136,7 +136,8 @@ class Trainer:
                 continue
             if info.world > 1:
                 d = DistributedDataParallel(g, bucket_mb=cfg.bucket_mb, mode=cfg.sync,
-                                            grad_dtype=torch.bfloat16 if cfg.grad_dtype == "bf16" else None)
+                                            grad_dtype=torch.bfloat16 if cfg.grad_dtype == "bf16" else None,
+                                            comm=cfg.comm if self.in_device.type == "cuda" else "torch")
                 if isinstance(model, StagedModel):
                     model.stages[gi] = d
                 else:

@@ -168,10 +168,11 @@ def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
         # The same loop with the collectives really issued over RCCL (identities at world 1): bucketed async
         # all-reduce launched from the gradient-ready notifications behind the side-stream wgrads, and the PS mode's
         # reduce-scatter -> sharded step -> all-gather.  Both must train exactly like the pass-through reducer.
-        def run(mode, force, wire=None):
+        def run(mode, force, wire=None, comm="torch"):
             torch.manual_seed(0)
             m = models.resnet18_cifar().to(_dev())
-            d = DistributedDataParallel(m, bucket_mb=2, mode=mode, force_collectives=force, grad_dtype=wire)
+            d = DistributedDataParallel(m, bucket_mb=2, mode=mode, force_collectives=force, grad_dtype=wire, comm=comm)
+            assert (d.ncomm is not None) == (comm == "native" and force)
             assert d.dist == force and len(d.arena.buckets) > 3
             o = FusedSGD(d.arena, lr=0.05, momentum=0.9)
             d.attach(o)
@@ -195,10 +196,13 @@ def test_rccl_world1_ddp_smoke_and_ps_mode(tmp_path):
             return ls, d.arena.master.clone()
 
         base, wb = run("allreduce", False)
-        for mode, wire in (("allreduce", None), ("ps", None), ("allreduce", torch.bfloat16), ("ps", torch.bfloat16)):
-            ls, w = run(mode, True, wire)
+        for mode, wire, comm in (("allreduce", None, "torch"), ("ps", None, "torch"),
+                                 ("allreduce", torch.bfloat16, "torch"), ("ps", torch.bfloat16, "torch"),
+                                 ("allreduce", None, "native"), ("ps", None, "native"),
+                                 ("ps", torch.bfloat16, "native")):
+            ls, w = run(mode, True, wire, comm)
             tol = 0.05 if wire is None else 0.25     # bf16-rounded gradients: same descent, looser trajectory
-            assert all(abs(a - b) < tol * max(1.0, abs(b)) for a, b in zip(ls, base)), (mode, wire, ls, base)
+            assert all(abs(a - b) < tol * max(1.0, abs(b)) for a, b in zip(ls, base)), (mode, wire, comm, ls, base)
             assert ls[-1] < 0.2 * ls[0]
             assert (w - wb).abs().max().item() < tol * wb.abs().max().item()
     finally:
@@ -402,3 +406,27 @@ def test_conv_relu_chain_gated_dgrad_matches_fp32_reference():
             assert float((got - want).norm() / (want.norm() + 1e-9)) < 0.3 and cos > 0.97
             # the fusion itself only moves the gate and the sums into another kernel: same values
             assert float((got - unf).norm() / (unf.norm() + 1e-9)) < 1e-3
+
+
+def test_native_rccl_communicator_world1_collectives():
+    """csrc/comm.cpp: RCCL resolved with dlopen from torch's copy, communicator init from a unique id, the four
+    collectives as identities at world 1 (fp32 and bf16), ordering against the compute stream through events."""
+    from distributed_deep_learning_amd.parallel.native_comm import NativeCommunicator
+    c = NativeCommunicator(0, 1, _dev())
+    assert c.version > 20000
+    for dt in (torch.float32, torch.bfloat16):
+        a = torch.randn(1 << 20, device=_dev()).to(dt)
+        ref = a.clone()
+        a.mul_(2.0)                                   # producer on the current stream: the collective must see it
+        c.all_reduce(a, average=True).wait()
+        assert torch.equal(a, ref * 2.0)
+        out = torch.empty_like(a)
+        c.reduce_scatter(out, a, average=False).wait()
+        assert torch.equal(out, a)
+        g = torch.zeros_like(a)
+        c.all_gather(g, a).wait()
+        assert torch.equal(g, a)
+        c.broadcast(a, 0).wait()
+        assert torch.equal(a, ref * 2.0)
+    torch.cuda.synchronize()
+    c.close()
