@@ -204,7 +204,9 @@ class Trainer:
         """The captured-graph path (``--graph``): single process, one device, fixed batch shape."""
         cfg = self.cfg
         want = cfg.graph if cfg.graph is not None else cfg.model in _GRAPH_AUTO_MODELS
-        ok = (want and self.info.world == 1 and cfg.mode in ("sequential", "data") and x.is_cuda
+        # several ranks: only on request, and only when the collectives can be captured (native communicator)
+        multi_ok = cfg.graph is True and cfg.comm == "native"
+        ok = (want and (self.info.world == 1 or multi_ok) and cfg.mode in ("sequential", "data") and x.is_cuda
               and len(self.optimizers) == 1 and hasattr(self.criterion, "last_correct"))
         if not ok:
             return None
@@ -214,7 +216,9 @@ class Trainer:
                 return None
             from .utils.graph import GraphedTrainStep
             y = y.to(x.device)
-            g = self._graphed = GraphedTrainStep(self.model, self.criterion, self.optimizers[0], x, y, warmup=1)
+            ddp = self.ddps[0] if self.ddps and self.ddps[0] is not None else None
+            model = ddp.module if ddp is not None else self.model
+            g = self._graphed = GraphedTrainStep(model, self.criterion, self.optimizers[0], x, y, warmup=1, ddp=ddp)
             self.global_step += 1                      # the warm-up step trained on this batch
             return g.warm_loss, g.warm_correct
         if x.shape != g.x.shape:

@@ -15,8 +15,11 @@ What makes the step capturable:
   replay (``optimizer.host_prepare``), so schedulers keep working;
 * the side-stream wgrad fork / join (``ops/streams.py``) happens inside the capture and becomes graph edges.
 
-Not supported inside the capture: multi-process gradient collectives (use eager mode with ``world > 1``), BN with
-``momentum=None`` (its factor depends on a host counter), data-dependent control flow.
+Gradient collectives can be part of the capture when they go through the native communicator
+(``DistributedDataParallel(comm="native")``: RCCL calls are plain stream operations there, the comm stream joins the
+capture through the usual event edges); collectives issued through ``torch.distributed`` are not captured — run
+those steps eagerly.  Also unsupported: BN with ``momentum=None`` (its factor depends on a host counter) and
+data-dependent control flow.
 """
 from __future__ import annotations
 
@@ -39,8 +42,14 @@ class GraphedTrainStep:
                  ddp=None):
         if not example_x.is_cuda:
             raise ValueError("GraphedTrainStep needs CUDA/HIP tensors")
-        if ddp is not None and ddp.dist:
-            raise NotImplementedError("graph capture with world_size > 1 is not supported: run the step eagerly")
+        if ddp is not None and ddp.dist and ddp.ncomm is None:
+            raise NotImplementedError("graph capture of torch.distributed collectives is not supported: build the "
+                                      "reducer with comm='native' or run the step eagerly")
+        if (ddp is not None and ddp.dist and ddp.mode == "ps" and getattr(optimizer, "norm_reduce", None) is not None
+                and optimizer.param_groups[0].get("lars")):
+            raise NotImplementedError("sharded LARS all-reduces its norms through torch.distributed: not capturable")
+        self.ddp = ddp if (ddp is not None and ddp.dist) else None
+        self.fwd = ddp if ddp is not None else model
         for m in model.modules():
             if isinstance(m, BatchNorm2d) and m.momentum is None:
                 raise NotImplementedError("BatchNorm with momentum=None cannot be captured")
@@ -67,8 +76,16 @@ class GraphedTrainStep:
         self.optimizer.host_prepare()
         with torch.cuda.graph(self.graph):
             self.loss = self._forward_backward()
-            streams.join()
-            self.optimizer.launch()
+            if self.ddp is not None:
+                d = self.ddp
+                d.finish_grad_sync()                 # waits = event edges from the communicator's stream
+                self.optimizer.launch(ranges=d.owned_ranges())
+                if d.mode == "ps":
+                    d.arena.zero_grad()
+                    d.gather_parameters()
+            else:
+                streams.join()
+                self.optimizer.launch()
         self.correct = getattr(self.criterion, "last_correct", None)
         # Capturing records the launches without running them: undo the host-side bookkeeping of that "step".
         self.optimizer.step_count -= 1
@@ -76,14 +93,17 @@ class GraphedTrainStep:
             bn._nbt_pending -= 1             # noqa: SLF001
 
     def _forward_backward(self) -> torch.Tensor:
-        out = self.model(self.x)
+        out = self.fwd(self.x)
         loss = self.criterion(out, self.y)
         loss.backward()
         return loss.detach()
 
     def _eager_step(self) -> torch.Tensor:
         loss = self._forward_backward()
-        self.optimizer.step()
+        if self.ddp is not None:
+            self.ddp.step(self.optimizer)
+        else:
+            self.optimizer.step()
         return loss
 
     def __call__(self, x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -430,3 +430,45 @@ def test_native_rccl_communicator_world1_collectives():
         assert torch.equal(a, ref * 2.0)
     torch.cuda.synchronize()
     c.close()
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "ps"])
+def test_hip_graph_captures_native_collectives(mode):
+    """A data-parallel step (bucketed reducer, native RCCL communicator, world 1 with the collectives forced) replays
+    from ONE hipGraph — kernels and collectives — along the eager reducer's trajectory."""
+    import os
+    import torch.distributed as td
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    from distributed_deep_learning_amd.utils import GraphedTrainStep
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
+    try:
+        x = torch.randn(32, 3, 32, 32, device=_dev())
+        y = torch.randint(0, 10, (32,), device=_dev())
+
+        def make():
+            torch.manual_seed(0)
+            m = models.resnet18_cifar().to(_dev())
+            d = DistributedDataParallel(m, bucket_mb=2, mode=mode, force_collectives=True, comm="native")
+            o = FusedSGD(d.arena, lr=0.02, momentum=0.9)
+            d.attach(o)
+            return m, d, o, SoftmaxCrossEntropyLoss()
+
+        m1, d1, o1, c1 = make()
+        eager = []
+        for _ in range(10):
+            loss = c1(d1(x), y)
+            loss.backward()
+            d1.step(o1)
+            eager.append(float(loss.detach()))
+        m2, d2, o2, c2 = make()
+        g = GraphedTrainStep(m2, c2, o2, x, y, warmup=2, ddp=d2)
+        graphed = [float(g(x, y)) for _ in range(8)]
+        assert graphed[-1] < graphed[0]
+        for a, b in zip(graphed, eager[2:]):
+            assert abs(a - b) < 0.15 * max(1.0, abs(b)), (graphed, eager)
+    finally:
+        td.destroy_process_group()
