@@ -46,7 +46,7 @@ def main() -> int:
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: issue the (identity) RCCL collectives of the DP reducer even on one GPU")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
-                    help="replay the whole step as one captured hipGraph (single-process runs only)")
+                    help="replay the whole step as one captured hipGraph (with several ranks: needs --comm native)")
     a = ap.parse_args()
 
     import torch
@@ -102,9 +102,10 @@ def main() -> int:
             opt.step()
         return loss
 
-    if a.graph == "on" and info.world == 1:
+    graph_on = a.graph == "on" and (ddp is None or not ddp.dist or a.comm == "native")
+    if graph_on:
         from distributed_deep_learning_amd.utils import GraphedTrainStep
-        graphed = GraphedTrainStep(model, crit, opt, x, y, warmup=2)
+        graphed = GraphedTrainStep(model, crit, opt, x, y, warmup=2, ddp=ddp)
 
         def step():                           # noqa: F811 - same work, replayed from the captured graph
             return graphed(x, y)
@@ -139,7 +140,7 @@ def main() -> int:
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random N(0,1) images, random-init weights)",
             "config": {"model": a.model, "global_batch": gb, "per_gpu_batch": a.batch, "image": image, "seq_len": None,
                        "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
-                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": a.comm, "hip_graph": a.graph == "on" and info.world == 1},
+                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": a.comm, "hip_graph": graph_on},
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S[a.batch], 3)
                                              if a.model == "resnet50" and a.batch in STOCK_PYTORCH_1GPU_IMG_S else None,
             "final_loss": round(final_loss, 4),
