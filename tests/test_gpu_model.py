@@ -472,3 +472,42 @@ def test_hip_graph_captures_native_collectives(mode):
             assert abs(a - b) < 0.15 * max(1.0, abs(b)), (graphed, eager)
     finally:
         td.destroy_process_group()
+
+
+def test_ledger_snapshot_on_vgg_chain_and_lenet():
+    """The conv-ReLU chain writes bias gradients from the NEXT unit's dgrad epilogue (slab fold into the arena) and
+    filter gradients on the side stream: the ledger's bucket snapshots prove that every one of them has landed before
+    its bucket's collective is enqueued (world 1, RCCL identity collectives)."""
+    import os
+    import torch.distributed as td
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    from distributed_deep_learning_amd.utils import GradLedger
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29651", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    td.init_process_group("nccl", rank=0, world_size=1, device_id=_dev())
+    try:
+        cases = [(models.vgg11(num_classes=10, input_size=32, hidden=256, dropout=0.0), (16, 3, 32, 32), 0.25),
+                 (models.lenet5(), (16, 1, 28, 28), 0.02)]
+        for model, shape, bucket_mb in cases:
+            torch.manual_seed(1)
+            m = model.to(_dev())
+            d = DistributedDataParallel(m, bucket_mb=bucket_mb, force_collectives=True)
+            assert len(d.arena.buckets) > 2
+            ledger = GradLedger(d, snapshot=True)
+            o = FusedSGD(d.arena, lr=0.01, momentum=0.9)
+            crit = SoftmaxCrossEntropyLoss()
+            x = torch.randn(*shape, device=_dev())
+            y = torch.randint(0, 10, (shape[0],), device=_dev())
+            first = None
+            for _ in range(4):
+                loss = crit(d(x), y)
+                loss.backward()
+                assert d._next_bucket == -1                         # noqa: SLF001 - all launched inside backward
+                d.step(o)
+                first = first if first is not None else float(loss.detach())
+            assert ledger.verified == 4 * len(d.arena.buckets) and not ledger.violations
+            assert float(loss.detach()) < first
+    finally:
+        td.destroy_process_group()
