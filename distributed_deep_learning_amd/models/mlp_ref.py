@@ -1,12 +1,17 @@
 """The reference's MLP workload: Linear(in->38)+ReLU, ``hidden_layers`` x [Linear(38->38)+ReLU], Linear(38->5)
 (``/root/reference/src/pytorch/MLP/model.py:51-59``); 48 input features for the MQTT data
 (``/root/reference/src/pytorch/MLP/dataset.py:33-37``).  Emits logits (the reference's trailing Softmax in front
-of CrossEntropyLoss is defect A5); 3,539 parameters at the default depth."""
+of CrossEntropyLoss is defect A5); 3,539 parameters at the default depth.  On the GPU the whole stack runs as ONE
+forward and ONE backward launch (``nn.functional.FusedMLP`` -> ``csrc/mlp.hip``); the staged (model-parallel /
+pipeline) paths and CPU tensors go layer by layer."""
 from __future__ import annotations
 
+import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
+from ..nn import functional as _F
+from ..ops import kernels as _K
 
 
 class MLPRef(tnn.Module):
@@ -26,6 +31,15 @@ class MLPRef(tnn.Module):
         return [FnStage(f, m) for f, m in zip(self.stages(), [*self.hidden, self.out])]
 
     def forward(self, x):
+        layers = [*self.hidden, self.out]
+        dims = [layers[0].in_features] + [l.out_features for l in layers]
+        if x.is_cuda and x.dim() == 2 and _K.mlp_supported(dims) and all(l.weight.dtype == x.dtype == torch.float32
+                                                                         for l in layers):
+            # GPU: the whole stack is one forward and one backward launch (csrc/mlp.hip), fp32 like the reference
+            params = []
+            for l in layers:
+                params += [l.weight, l.bias]
+            return _F.FusedMLP.apply(x, False, *params)
         for s in self.stages():
             x = s(x)
         return x

@@ -432,6 +432,55 @@ class ConvReluChain(torch.autograd.Function):
         return (d, None, *grads)
 
 
+class FusedMLP(torch.autograd.Function):
+    """A whole stack of ``Linear (+ ReLU)`` layers up to 64 wide in ONE forward and ONE backward launch
+    (``csrc/mlp.hip``), fp32.  ``FusedMLP.apply(x, relu_last, w0, b0, w1, b1, ...)``; ReLU follows every layer but the
+    last (and the last too with ``relu_last``).  Parameter gradients are accumulated straight into the arena when the
+    parameters live there (else returned to autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, relu_last, *params):
+        ws, bs = list(params[0::2]), list(params[1::2])
+        xf = x.float().contiguous()
+        need = any(ctx.needs_input_grad)
+        out, acts = K.mlp_fwd(xf, [w.detach() for w in ws], [None if b is None else b.detach() for b in bs],
+                              relu_last=relu_last, save=need)
+        if need:
+            ctx.save_for_backward(out, acts)
+            ctx.params = (ws, bs)
+            ctx.relu_last = relu_last
+            ctx.x_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        out, acts = ctx.saved_tensors
+        ws, bs = ctx.params
+        direct, gw, gb = [], [], []
+        for p in ws + bs:                                   # arena-backed parameters: accumulate in place
+            arena = getattr(p, "_ddl_arena", None) if p is not None else None
+            direct.append(p is not None and arena is not None and arena.grad_is_arena_view(p) and p.grad.is_contiguous())
+        n = len(ws)
+        for i, w in enumerate(ws):
+            gw.append(w.grad if direct[i] else (torch.zeros_like(w, dtype=torch.float32) if w.requires_grad else None))
+        for i, b in enumerate(bs):
+            if b is None:
+                gb.append(None)
+            else:
+                gb.append(b.grad if direct[n + i] else (torch.zeros_like(b, dtype=torch.float32) if b.requires_grad else None))
+        dx = K.mlp_bwd(dout.float().contiguous(), out, acts, [w.detach() for w in ws], gw, gb, relu_last=ctx.relu_last,
+                       want_dx=ctx.needs_input_grad[0])
+        grads = []
+        for i in range(n):
+            for p, g, d in ((ws[i], gw[i], direct[i]), (bs[i], gb[i], direct[n + i])):
+                if p is not None and d:
+                    p._ddl_arena.notify_grad_ready(p)       # noqa: SLF001
+                    grads.append(None)
+                else:
+                    grads.append(g)
+        return (dx.to(ctx.x_dtype) if dx is not None else None, None, *grads)
+
+
 class BNAct(torch.autograd.Function):
     """Stand-alone training BatchNorm (+ residual)(+ ReLU) for inputs not produced by our conv (e.g. concat)."""
 

@@ -67,6 +67,8 @@ _SIGS = {
     "ddl_comm_reduce_scatter": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "ddl_comm_all_gather": [_vp, _vp, _vp, _ll, _i, _vp],
     "ddl_comm_broadcast": [_vp, _vp, _ll, _i, _i, _vp],
+    "ddl_mlp_fwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp],
+    "ddl_mlp_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "ddl_lstm_supported": [_i, _i],
     "ddl_lstm_fwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ddl_lstm_bwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

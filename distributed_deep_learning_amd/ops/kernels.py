@@ -543,6 +543,58 @@ def s2d_filter(w: torch.Tensor) -> torch.Tensor:
     return torch.nn.functional.pad(w12, (0, 0, 0, 0, 0, 4))             # [K,16,4,4]
 
 
+# ----------------------------------------------------------------------------------------------- fused small MLP
+MLP_MAX_WIDTH, MLP_MAX_LAYERS, _MLP_LDS_FLOATS = 64, 8, (160 * 1024) // 4 - 3 * 64 * 33
+
+
+def mlp_supported(dims) -> bool:
+    """Layer widths ``dims = [in, h1, ..., out]`` the fused MLP kernels take (constants mirror csrc/mlp.hip)."""
+    L = len(dims) - 1
+    params = sum(dims[i + 1] * dims[i] + dims[i + 1] for i in range(L))
+    return 1 <= L <= MLP_MAX_LAYERS and all(1 <= d <= MLP_MAX_WIDTH for d in dims) and params + 4 <= _MLP_LDS_FLOATS
+
+
+def _ptr_array(tensors):
+    import ctypes as C
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def mlp_fwd(x, weights, biases, relu_last=False, save=True):
+    """Whole Linear(+ReLU) stack in one launch.  ``x`` fp32 ``[B, in]``; ``weights[l]`` fp32 ``[out_l, in_l]``
+    contiguous, ``biases[l]`` fp32 or ``None``.  Returns ``(out [B, out], acts [B, sum(in_l)] or None)``."""
+    import ctypes as C
+    lib = _lib.require()
+    dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    if x.dtype != torch.float32 or not x.is_contiguous() or x.shape[1] != dims[0]:
+        raise ValueError("mlp_fwd: x must be a contiguous fp32 [B, in] tensor")
+    if not mlp_supported(dims) or any(w.dtype != torch.float32 or not w.is_contiguous() for w in weights):
+        raise ValueError("mlp_fwd: unsupported layer stack (see mlp_supported) or non-fp32 / non-contiguous weights")
+    B = x.shape[0]
+    out = torch.empty((B, dims[-1]), dtype=torch.float32, device=x.device)
+    acts = torch.empty((B, sum(dims[:-1])), dtype=torch.float32, device=x.device) if save else None
+    check(lib.ddl_mlp_fwd(ptr(x), _ptr_array(weights), _ptr_array(biases), (C.c_int * len(dims))(*dims), len(weights),
+                          int(relu_last), ptr(acts), ptr(out), B, stream_ptr()), "mlp_fwd")
+    return out, acts
+
+
+def mlp_bwd(dout, out, acts, weights, dweights, dbiases, relu_last=False, want_dx=False):
+    """Backward of :func:`mlp_fwd`: ``dweights[l]`` / ``dbiases[l]`` (fp32, parameter layouts, or ``None``) are
+    ACCUMULATED into; returns ``dx`` (``[B, in]``) when asked for."""
+    import ctypes as C
+    lib = _lib.require()
+    dims = [weights[0].shape[1]] + [w.shape[0] for w in weights]
+    B = dout.shape[0]
+    if dout.dtype != torch.float32 or not dout.is_contiguous() or tuple(dout.shape) != (B, dims[-1]):
+        raise ValueError("mlp_bwd: dout must be a contiguous fp32 [B, out] tensor")
+    for g, w in zip(dweights, weights):
+        if g is not None and (g.dtype != torch.float32 or not g.is_contiguous() or g.shape != w.shape):
+            raise ValueError("mlp_bwd: weight-gradient buffers must match the weights (fp32, contiguous)")
+    dx = torch.empty((B, dims[0]), dtype=torch.float32, device=dout.device) if want_dx else None
+    check(lib.ddl_mlp_bwd(ptr(dout), ptr(out), ptr(acts), _ptr_array(weights), _ptr_array(dweights), _ptr_array(dbiases),
+                          (C.c_int * len(dims))(*dims), len(weights), int(relu_last), ptr(dx), B, stream_ptr()), "mlp_bwd")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------- recurrent
 def lstm_supported(hidden: int, inputs: int) -> bool:
     """Shapes with a compiled instance of the fused LSTM layer (constants mirrored from csrc/lstm.hip)."""

@@ -508,3 +508,53 @@ def test_dgrad_epilogue_bn_backward_sums(case):
     _close(got[2], ref[2], rtol=2e-3, atol=2e-3 * scale, what="dgamma from epilogue sums")
     _close(got[3], ref[3], rtol=2e-3, atol=2e-3 * scale, what="dbeta from epilogue sums")
     _close(got[0], ref[0], rtol=2e-2, atol=2e-2, what="dx from epilogue sums")
+
+
+# ----------------------------------------------------------------------------------------------- fused small MLP
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,dims,relu_last", [(32, [48, 38, 38, 5], False), (300, [48, 38, 38, 38, 5], False),
+                                              (129, [7, 64, 1], True), (1000, [64, 64, 64, 64, 10], False)])
+def test_fused_mlp_matches_torch_fp32(B, dims, relu_last):
+    """csrc/mlp.hip (whole Linear+ReLU stack in one forward and one backward launch) vs torch.nn in fp32."""
+    from distributed_deep_learning_amd.nn.functional import FusedMLP
+    torch.manual_seed(4)
+    layers = [torch.nn.Linear(a, b).cuda() for a, b in zip(dims[:-1], dims[1:])]
+    x = torch.randn(B, dims[0], device="cuda", requires_grad=True)
+    h = x
+    for i, l in enumerate(layers):
+        h = l(h)
+        if i + 1 < len(layers) or relu_last:
+            h = torch.relu(h)
+    w = torch.randn_like(h)
+    (h * w).sum().backward()
+    want = [x.grad.clone()] + [p.grad.clone() for l in layers for p in (l.weight, l.bias)]
+    x.grad = None
+    for l in layers:
+        l.weight.grad = l.bias.grad = None
+    params = [p for l in layers for p in (l.weight, l.bias)]
+    out = FusedMLP.apply(x, relu_last, *params)
+    assert torch.allclose(out, h.detach(), rtol=1e-4, atol=1e-5)
+    (out * w).sum().backward()
+    got = [x.grad] + [p.grad for p in params]
+    for g, r in zip(got, want):
+        assert g is not None and torch.allclose(g, r, rtol=2e-4, atol=2e-4 * float(r.abs().max() + 1e-6)), (g - r).abs().max()
+
+
+@pytest.mark.gpu
+def test_fused_mlp_accumulates_into_the_arena():
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.parallel import ParamArena
+    torch.manual_seed(0)
+    m = models.build("mlp").cuda()
+    ref = models.build("mlp")
+    ref.load_state_dict(m.state_dict())
+    arena = ParamArena(m.named_parameters())
+    x = torch.randn(200, 48)
+    y = torch.randint(0, 5, (200,))
+    torch.nn.functional.cross_entropy(ref(x), y).backward()
+    out = m(x.cuda())
+    assert "FusedMLP" in type(out.grad_fn).__name__
+    torch.nn.functional.cross_entropy(out, y.cuda()).backward()
+    for (n, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert arena.grad_is_arena_view(p), n
+        assert torch.allclose(p.grad.cpu(), q.grad, rtol=1e-3, atol=1e-5), n
