@@ -189,13 +189,13 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
 #pragma unroll
     for (int k = 0; k < 4; ++k) s.g[k] = *reinterpret_cast<const u32x2*>(gp + k * H);
     s.d = *reinterpret_cast<const u32x2*>(dbase + t * d_st);
-    s.c = *reinterpret_cast<const f32x4*>(cbase + (size_t)(t + 1) * H);
-    s.cp = *reinterpret_cast<const f32x4*>(cbase + (size_t)t * H);
+    s.cp = *reinterpret_cast<const f32x4*>(cbase + (size_t)t * H);   // c_{t-1}; c_t is the previous step's cp
     return s;
   };
 
   float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
   Step s = fetch(T - 1);
+  s.c = *reinterpret_cast<const f32x4*>(cbase + (size_t)T * H);
   int cur = 0;
   for (int t = T - 1; t >= 0; --t) {
     float gi[4], gf[4], gg[4], go[4], dy[4];
@@ -228,7 +228,11 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
       *reinterpret_cast<u32x2*>(gp + 2 * H) = pg;
       *reinterpret_cast<u32x2*>(gp + 3 * H) = po;
     }
-    if (t > 0) s = fetch(t - 1);                    // next step's operands fly during the MFMA phase
+    if (t > 0) {                                    // every cell state is read once: this step's c_{t-1} is the next c_t
+      const f32x4 c_next = s.cp;
+      s = fetch(t - 1);
+      s.c = c_next;
+    }                    // next step's operands fly during the MFMA phase
     __syncthreads();
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
