@@ -358,7 +358,7 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
     }
   if (any_empty && (addend != nullptr || stats != nullptr)) return -4;   // zero-filled pixels would miss the epilogue
   if (any_empty) {   // classes without a contributing tap (e.g. 1x1 stride-2) are plain zeros
-    hipError_t e = hipMemsetAsync(out, 0, sizeof(bf16_t) * (size_t)M * (size_t)OC, st);
+    hipError_t e = ddl_zero_async(out, sizeof(bf16_t) * (size_t)M * (size_t)OC, st);
     if (e != hipSuccess) return (int)e;
   }
   for (int ph = 0; ph < stride; ++ph)

@@ -282,7 +282,7 @@ static int launch_bias_grad(const void* dy, const void* y, void* dx, float* db, 
                             hipStream_t st) {
   if (C % 8 != 0 || M <= 0) return -1;
   if (!accumulate) {
-    hipError_t e = hipMemsetAsync(db, 0, sizeof(float) * (size_t)C, st);
+    hipError_t e = ddl_zero_async(db, sizeof(float) * (size_t)C, st);
     if (e != hipSuccess) return (int)e;
   }
   const int c8 = C / 8, cpb = c8 <= 256 ? c8 : 256, rp = 256 / cpb;

@@ -37,3 +37,17 @@ static inline unsigned int grid_for(long long work_items, int per_block, int max
   if (b > max_blocks) b = max_blocks;
   return (unsigned int)b;
 }
+
+// Zero-fill as a KERNEL, never hipMemsetAsync: inside a captured hipGraph a memset NODE on a small buffer of the
+// graph's private pool went wrong after torch.cuda.empty_cache() (replays produced garbage; found with LeNet-5's
+// padded-bias path, the only one that zero-filled through a memset while captured).  A fill kernel is an ordinary
+// kernel node.  `bytes` must be a multiple of 4.
+static __global__ void ddl_zero_kernel(unsigned int* __restrict__ p, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline hipError_t ddl_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const size_t n = bytes / 4;
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(ddl_zero_kernel, dim3(grid_for((long long)n, 256)), dim3(256), 0, st, (unsigned int*)p, n);
+  return hipGetLastError();
+}

@@ -129,7 +129,7 @@ extern "C" int ddl_chunk_elems() { return DDL_CHUNK; }
 extern "C" int ddl_flat_sumsq(const float* w, const float* g, const int* chunk_seg, float* norms, int nseg,
                               int chunk_begin, int chunk_end, void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(norms, 0, sizeof(float) * 2 * (size_t)nseg, st);
+  hipError_t e = ddl_zero_async(norms, sizeof(float) * 2 * (size_t)nseg, st);
   if (e != hipSuccess) return (int)e;
   if (chunk_end <= chunk_begin) return 0;
   hipLaunchKernelGGL(flat_sumsq_kernel, dim3(chunk_end - chunk_begin), dim3(256), 0, st, w, g, chunk_seg, norms,

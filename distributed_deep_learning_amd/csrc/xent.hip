@@ -89,7 +89,7 @@ extern "C" int ddl_softmax_xent(const void* logits, int is_bf16, const long long
                                 void* dlogits, float* out, int B, int V, void* stream) {
   if (B <= 0 || V <= 0 || ((labels == nullptr) == (probs == nullptr))) return -1;
   hipStream_t s = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(float), s);
+  hipError_t e = ddl_zero_async(out, 2 * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
   const dim3 grid((B + 3) / 4), block(256);
   const float inv_b = 1.f / (float)B;

@@ -479,8 +479,8 @@ def relu_bwd_bias_grad(dy, y, grad_out=None):
             raise ValueError("relu_bwd_bias_grad: grad_out must be a contiguous fp32 [C] tensor")
         db = grad_out
     else:
-        db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
-    check(lib.ddl_relu_bwd_bias_grad(ptr(dy), ptr(y), ptr(dx), ptr(db), N * H * W, Cc, int(grad_out is not None),
+        db = torch.zeros(Cc, dtype=torch.float32, device=dy.device)     # zeroed by a fill kernel, kernel accumulates
+    check(lib.ddl_relu_bwd_bias_grad(ptr(dy), ptr(y), ptr(dx), ptr(db), N * H * W, Cc, 1,
                                      stream_ptr()), "relu_bwd_bias_grad")
     return dx, db
 

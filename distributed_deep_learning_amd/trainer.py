@@ -239,6 +239,25 @@ class Trainer:
                 print(f"[fault drill] rank {r} exits before step {st}", file=sys.stderr, flush=True)
                 os._exit(17)
 
+    def _graph_eval(self, x, y):
+        """Evaluation batch through a captured forward graph (same switch as the training graph; one graph per batch
+        shape, so the ragged last batch of a split gets its own or runs eagerly)."""
+        cfg = self.cfg
+        want = cfg.graph if cfg.graph is not None else cfg.model in _GRAPH_AUTO_MODELS
+        if not (want and cfg.mode in ("sequential", "data") and x.is_cuda and len(self.optimizers) == 1
+                and hasattr(self.criterion, "last_correct")):
+            return None
+        cache = self.__dict__.setdefault("_graphed_eval", {})
+        key = (tuple(x.shape), tuple(y.shape), x.dtype, y.dtype)
+        g = cache.get(key)
+        if g is None:
+            if len(cache) >= 4 or x.shape[0] != cfg.batch:
+                return None
+            from .utils.graph import GraphedEvalStep
+            model = self.model.module if isinstance(self.model, DistributedDataParallel) else self.model
+            g = cache[key] = GraphedEvalStep(model, self.criterion, x, y.to(x.device))
+        return g(x, y.to(x.device))
+
     def train_step(self, x, y):
         self._maybe_die()
         out = self._graph_step(x, y)
@@ -282,7 +301,8 @@ class Trainer:
                     loss, correct = self.train_step(x, y)
                     timer.tick()
                 else:
-                    loss, correct = self._forward_loss(x, y)
+                    out = self._graph_eval(x, y)
+                    loss, correct = out if out is not None else self._forward_loss(x, y)
                 meter.update(loss, correct, len(x))
         acc, loss, n, dt = meter.result(reduce=self.cfg.global_metrics)
         return acc, loss, n, dt, (timer.summary() if timer else {})

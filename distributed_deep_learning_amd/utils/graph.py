@@ -116,3 +116,49 @@ class GraphedTrainStep:
         self.optimizer.host_finish()
         self.replays += 1
         return self.loss
+
+
+class GraphedEvalStep:
+    """Forward + loss of an evaluation batch (``model.eval()``, no gradients) as one hipGraph:
+    ``ev = GraphedEvalStep(model, criterion, x0, y0); loss, correct = ev(x, y)``.
+
+    The validation / test passes of the small workloads are as launch-bound as their training step (a third of an
+    epoch's wall time for the reference's 70/10/20 split once the training step is graphed).  Eval-mode BatchNorm
+    derives its affine from the running statistics INSIDE the graph, so a replay always sees the current buffers.
+    The model must already be in eval mode; outputs are static tensors overwritten by the next replay."""
+
+    def __init__(self, model, criterion, example_x: torch.Tensor, example_y: torch.Tensor):
+        if not example_x.is_cuda:
+            raise ValueError("GraphedEvalStep needs CUDA/HIP tensors")
+        if model.training:
+            raise ValueError("GraphedEvalStep captures the eval-mode forward: call model.eval() first")
+        self.model, self.criterion = model, criterion
+        self.x, self.y = example_x.clone(), example_y.clone()
+        self.graph = torch.cuda.CUDAGraph()
+        self.replays = 0
+        s = torch.cuda.Stream(device=example_x.device)
+        s.wait_stream(torch.cuda.current_stream(example_x.device))
+        with torch.cuda.stream(s), torch.no_grad():
+            self._forward()                                   # warm-up: allocator pools, lazily-built caches
+        torch.cuda.current_stream(example_x.device).wait_stream(s)
+        torch.cuda.synchronize(example_x.device)
+        # Derived weight copies (bf16 packs of filters / Linear weights not backed by the arena shadow) are cached per
+        # weights epoch; the warm-up just refreshed them, so a capture would bake in the addresses of copies that later
+        # training makes stale.  Bumping the epoch forces every such copy to be re-derived INSIDE the graph.
+        from ..ops import state as _state
+        _state.bump()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.loss = self._forward()
+        _state.bump()       # ...and the copies cached DURING the capture live in the graph's pool (filled only by replays):
+        #                     invalidate them for every eager caller
+        self.correct = getattr(self.criterion, "last_correct", None)
+
+    def _forward(self) -> torch.Tensor:
+        return self.criterion(self.model(self.x), self.y).detach()
+
+    def __call__(self, x: torch.Tensor, y: torch.Tensor):
+        self.x.copy_(x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        return self.loss, self.correct

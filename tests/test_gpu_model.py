@@ -511,3 +511,71 @@ def test_ledger_snapshot_on_vgg_chain_and_lenet():
             assert float(loss.detach()) < first
     finally:
         td.destroy_process_group()
+
+
+@pytest.mark.parametrize("name,shape,classes", [("cnn", (32, 3, 64, 64), 6), ("lenet5", (32, 1, 28, 28), 10)])
+def test_graphed_eval_step_tracks_training(name, shape, classes):
+    """GraphedEvalStep: the captured eval forward gives the eager eval loss — also AFTER more training steps changed
+    the weights and the BN running statistics (nothing stale is baked into the graph)."""
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+    from distributed_deep_learning_amd.utils import GraphedEvalStep
+    torch.manual_seed(0)
+    m = models.build(name).to(_dev())
+    arena = ParamArena(m.named_parameters())
+    opt = FusedSGD(arena, lr=0.05, momentum=0.9)
+    crit = SoftmaxCrossEntropyLoss()
+    x = torch.randn(*shape, device=_dev())
+    y = torch.randint(0, classes, (shape[0],), device=_dev())
+
+    def train(k):
+        m.train()
+        for _ in range(k):
+            crit(m(x), y).backward()
+            opt.step()
+        m.eval()
+
+    train(2)
+    ev = GraphedEvalStep(m, crit, x, y)
+    seen = []
+    for _ in range(3):
+        with torch.no_grad():
+            want = float(crit(m(x), y))
+        got, correct = ev(x, y)
+        assert abs(float(got) - want) < 2e-3 * max(1.0, abs(want)), (float(got), want)
+        assert correct is not None
+        seen.append(want)
+        train(3)
+    assert seen[-1] < seen[0]                      # the evaluated model did change between the replays
+
+
+def test_train_graph_survives_empty_cache_and_a_second_capture():
+    """Regression: a captured hipMemsetAsync (memset node on a small graph-pool buffer; LeNet-5's padded-bias gradient
+    was the only captured user) made replays produce garbage after torch.cuda.empty_cache() — which every later
+    torch.cuda.graph capture calls.  All zero fills of the kernel library are fill kernels now."""
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+    from distributed_deep_learning_amd.utils import GraphedEvalStep, GraphedTrainStep
+    torch.manual_seed(0)
+    m = models.lenet5().to(_dev())
+    arena = ParamArena(m.named_parameters())
+    opt = FusedSGD(arena, lr=0.05, momentum=0.9)
+    crit = SoftmaxCrossEntropyLoss()
+    x = torch.randn(64, 1, 28, 28, device=_dev())
+    y = torch.randint(0, 10, (64,), device=_dev())
+    g = GraphedTrainStep(m, crit, opt, x, y, warmup=1)
+    a = [float(g(x, y)) for _ in range(3)]
+    torch.cuda.empty_cache()
+    b = [float(g(x, y)) for _ in range(3)]
+    m.eval()
+    ev = GraphedEvalStep(m, SoftmaxCrossEntropyLoss(), x, y)      # a second capture (gc + empty_cache inside)
+    e = float(ev(x, y)[0])
+    m.train()
+    c = [float(g(x, y)) for _ in range(3)]
+    seq = a + b + c
+    assert all(v == v and v < 3.0 for v in seq + [e]), (seq, e)
+    assert seq[-1] < seq[0]
