@@ -3,18 +3,26 @@
 random-init weights — the metric/config BASELINE.json names.
 
     python bench.py --gpus 1 --steps 30 --warmup 10
+    python bench.py --gpus 8 --steps 30 --warmup 10          # starts its own 8 ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               # or under an external launcher
 
-One rank per GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  A step is the full
-training step: input conversion, forward, loss, backward with bucketed gradient all-reduce overlapped on RCCL's
-stream, fused SGD-momentum update of fp32 masters + bf16 shadow.  W untimed warm-up steps, then exactly K steps
-between barrier + synchronize on both sides; the reported time is the MAX over ranks.  Weak scaling: the per-GPU
-batch is fixed.  Rank 0 prints ONE JSON line.
+One rank per GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Without a launcher
+environment ``--gpus N`` (N > 1) makes THIS process a launcher: it checks the GPU count without touching HIP, then
+starts N child ranks of this same script on 127.0.0.1 and waits for them (the reference launches its own ranks the
+same way: ``torch.multiprocessing.spawn(process, nprocs=GLOBAL_WORLD)``,
+``/root/reference/src/pytorch/CNN/main.py:197-203``).  Too few GPUs is an error, never a silent 1-GPU record.
+
+A step is the full training step: input conversion, forward, loss, backward with bucketed gradient all-reduce
+overlapped on the communicator's stream, fused SGD-momentum update of fp32 masters + bf16 shadow.  W untimed warm-up
+steps, then exactly K steps between barrier + synchronize on both sides; the reported time is the MAX over ranks.
+Weak scaling: the per-GPU batch is fixed.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,7 +34,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6793.5}
 
 
-def main() -> int:
+def build_parser() -> argparse.ArgumentParser:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -41,14 +49,76 @@ def main() -> int:
     ap.add_argument("--image", type=int, default=224)
     ap.add_argument("--grad-dtype", default="fp32", choices=["fp32", "bf16"],
                     help="wire format of the gradient collectives (fp32 = in place on the arena, the default)")
-    ap.add_argument("--comm", default="torch", choices=["torch", "native"],
-                    help="collectives through torch.distributed (default) or the native RCCL communicator (csrc/comm.cpp)")
+    ap.add_argument("--comm", default="native", choices=["torch", "native"],
+                    help="collectives through the native RCCL communicator (csrc/comm.cpp, default; checked against "
+                         "torch.distributed at start-up, which takes over if the check fails) or torch.distributed")
     ap.add_argument("--force-collectives", action="store_true",
                     help="diagnostic: issue the (identity) RCCL collectives of the DP reducer even on one GPU")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay the whole step as one captured hipGraph (with several ranks: needs --comm native)")
-    a = ap.parse_args()
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launch only: seconds after which the launcher kills its ranks and fails")
+    ap.add_argument("--watchdog-s", type=float, default=120.0,
+                    help="reducer watchdog: a gradient collective pending longer than this aborts the rank with a report")
+    return ap
 
+
+# ----------------------------------------------------------------------------------------------- launcher
+def _free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(a, argv) -> int:
+    """``--gpus N`` with no launcher environment: start N ranks of this script.  Nothing here touches the GPU
+    (``device_count`` reads the driver's device list without creating a HIP context), the children are fresh
+    processes — never an exec of a process that already initialised HIP."""
+    import torch
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this machine shows {have} - refusing to report a "
+              f"{have}-GPU number as an {a.gpus}-GPU one", file=sys.stderr, flush=True)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DDL_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    deadline = time.monotonic() + a.launch_timeout
+    rc = 0
+    live = set(range(a.gpus))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print(f"bench.py launcher: rank {r} exited with code {code}; stopping the other ranks",
+                      file=sys.stderr, flush=True)
+        if rc != 0 or time.monotonic() > deadline:
+            if rc == 0:
+                rc = 124
+                print(f"bench.py launcher: ranks {sorted(live)} still running after {a.launch_timeout:.0f} s; killing them",
+                      file=sys.stderr, flush=True)
+            for r in live:
+                procs[r].terminate()
+            t_end = time.monotonic() + 10
+            for r in live:
+                try:
+                    procs[r].wait(max(0.1, t_end - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        time.sleep(0.2)
+    return rc
+
+
+# ----------------------------------------------------------------------------------------------- one rank
+def run_rank(a) -> int:
     import torch
     import torch.distributed as td
 
@@ -60,11 +130,14 @@ def main() -> int:
 
     info = ddist.discover()
     if info.world != a.gpus:
-        if info.world == 1 and a.gpus > 1:
-            print(f"bench.py: --gpus {a.gpus} needs a launcher (torch.distributed.run); running on 1 GPU", file=sys.stderr)
-        a.gpus = info.world
+        print(f"bench.py: --gpus {a.gpus} but the launcher environment says WORLD_SIZE={info.world}", file=sys.stderr)
+        return 2
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible", file=sys.stderr)
+        return 2
+    if torch.cuda.device_count() <= info.local_rank:
+        print(f"bench.py: rank {info.rank} wants cuda:{info.local_rank}, only {torch.cuda.device_count()} GPU(s) visible",
+              file=sys.stderr)
         return 2
     dev = torch.device(f"cuda:{info.local_rank}")
     ddist.init(info, dev, force=a.force_collectives)
@@ -74,10 +147,13 @@ def main() -> int:
     image = 32 if a.model == "resnet18_cifar" else a.image
     model = models.build(a.model).to(dev)
     ddp = None
+    comm_note = None
     if info.world > 1 or a.force_collectives:
         ddp = DistributedDataParallel(model, bucket_mb=a.bucket_mb, mode=a.sync, force_collectives=a.force_collectives,
-                                      grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else None, comm=a.comm)
+                                      grad_dtype=torch.bfloat16 if a.grad_dtype == "bf16" else None, comm=a.comm,
+                                      watchdog_s=a.watchdog_s)
         arena = ddp.arena
+        comm_note = ddp.comm_note
     else:
         arena = ParamArena(model.named_parameters(), bucket_bytes=int(a.bucket_mb * 2**20))
     if a.optimizer == "lars":
@@ -102,7 +178,7 @@ def main() -> int:
             opt.step()
         return loss
 
-    graph_on = a.graph == "on" and (ddp is None or not ddp.dist or a.comm == "native")
+    graph_on = a.graph == "on" and (ddp is None or not ddp.dist or ddp.ncomm is not None)
     if graph_on:
         from distributed_deep_learning_amd.utils import GraphedTrainStep
         graphed = GraphedTrainStep(model, crit, opt, x, y, warmup=2, ddp=ddp)
@@ -122,16 +198,19 @@ def main() -> int:
     for _ in range(a.steps):
         loss = step()
     fence()
-    dt = time.perf_counter() - t0
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dt_local = time.perf_counter() - t0
+    tmax = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+    tmin = tmax.clone()
     if info.world > 1:
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-    dt = float(t.item())
+        td.all_reduce(tmax, op=td.ReduceOp.MAX)
+        td.all_reduce(tmin, op=td.ReduceOp.MIN)
+    dt = float(tmax.item())
     final_loss = float(loss.detach().float().item())
 
     if info.rank == 0:
         gb = a.batch * info.world
         value = gb * a.steps / dt
+        comm_used = "none" if ddp is None or not ddp.dist else ("native" if ddp.ncomm is not None else "torch")
         rec = {
             "metric": "images/sec (whole job) ResNet-50 synthetic 224x224 training" if a.model == "resnet50"
                       else f"images/sec (whole job) {a.model} training",
@@ -140,15 +219,36 @@ def main() -> int:
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic (random N(0,1) images, random-init weights)",
             "config": {"model": a.model, "global_batch": gb, "per_gpu_batch": a.batch, "image": image, "seq_len": None,
                        "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
-                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": a.comm, "hip_graph": graph_on},
+                       "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": comm_used, "hip_graph": graph_on},
+            "rccl_ranks": (ddp.comm_ranks() if ddp is not None and ddp.dist else 1),
+            "ms_per_step_rank_min": round(1e3 * float(tmin.item()) / a.steps, 3),
+            "ms_per_step_rank_max": round(1e3 * dt / a.steps, 3),
+            "bucket_plan_mib": [round((b.hi - b.lo) * 4 / 2**20, 2) for b in arena.buckets],
+            "launcher": "self" if os.environ.get("DDL_BENCH_SELF_LAUNCHED") else info.launcher,
+            "comm_note": comm_note,
             "vs_stock_pytorch_rocm_per_gpu": round(value / info.world / STOCK_PYTORCH_1GPU_IMG_S[a.batch], 3)
                                              if a.model == "resnet50" and a.batch in STOCK_PYTORCH_1GPU_IMG_S else None,
             "final_loss": round(final_loss, 4),
             "note": "reference publishes no numbers (BASELINE.md); comparator = stock PyTorch-ROCm measured on the same MI355X",
         }
         print(json.dumps(rec), flush=True)
+    if ddp is not None:
+        ddp.close()
     ddist.shutdown()
     return 0
+
+
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else list(argv)
+    a = build_parser().parse_args(argv)
+    if a.gpus < 1:
+        print("bench.py: --gpus must be >= 1", file=sys.stderr)
+        return 2
+    from distributed_deep_learning_amd import dist as ddist
+    info = ddist.discover()
+    if info.world == 1 and a.gpus > 1 and info.launcher == "none":
+        return self_launch(a, argv)
+    return run_rank(a)
 
 
 if __name__ == "__main__":

@@ -4,8 +4,9 @@ The model part is a plain ``state_dict`` with stock PyTorch / torchvision key na
 a checkpoint written here loads into ``torchvision.models.resnet50()`` and vice versa (the channels-last / KRSC
 physical layout and the bf16 shadow are internal).  Rank 0 writes atomically (tmp + rename); every rank loads,
 then the DP wrapper re-broadcasts so replicas cannot diverge.  Optimizer state is stored flat with a name->range
-layout table, so it can be restored under a different bucket plan or world size (PS shards are gathered first:
-every rank holds the full fp32 master after ``gather_parameters``).
+layout table, so it can be restored under a different bucket plan or world size.  In the PS / ZeRO-1 mode the caller
+runs ``reducer.prepare_checkpoint()`` (exact fp32 masters of every shard on every rank) and ``optimizer.state_dict()``
+(a collective that all-gathers the momentum / Adam shards) on EVERY rank before rank 0 writes — see ``Trainer.save``.
 """
 from __future__ import annotations
 
@@ -60,7 +61,9 @@ def save(path: str, model, optimizer=None, scheduler=None, epoch: int = 0, step:
 def load(path: str, model, optimizer=None, scheduler=None, sampler=None, strict: bool = True,
          restore_rng: bool = False) -> Dict[str, Any]:
     """Load on every rank.  Returns the metadata dict (``epoch``, ``step``, ``extra``)."""
-    payload = torch.load(path, map_location="cpu", weights_only=False)
+    # weights_only: the payload is tensors, numbers, strings, lists, dicts and tuples only, so nothing from the file is
+    # ever executed (a checkpoint can come from an untrusted place)
+    payload = torch.load(path, map_location="cpu", weights_only=True)
     if payload.get("format") != FORMAT_VERSION:
         raise ValueError(f"unsupported checkpoint format {payload.get('format')}")
     model.load_state_dict(payload["model"], strict=strict)

@@ -26,7 +26,7 @@ class Config:
     epochs: int = 10                   # -e
     batch: int = 32                    # -b  per-rank batch size
     device: str = "cpu"                # -d  cpu | gpu
-    nworkers: int = 0                  # -w  (kept for CLI parity; batches are assembled on-device)
+    nworkers: int = 0                  # -w  loader threads assembling pinned host batches ahead (file-backed data)
     mode: str = "sequential"           # -m  sequential | model | pipeline | data
     pipeline: int = 2                  # -p  micro-batch size
     run: int = 1                       # -r  local ranks to spawn for -m data
@@ -46,7 +46,7 @@ class Config:
     sync: str = "allreduce"            # gradient sync: all-reduce | ps (reduce-scatter / all-gather)
     bucket_mb: float = 32.0
     grad_dtype: str = "fp32"           # wire format of the gradient collectives: fp32 (in place) | bf16
-    comm: str = "torch"                # collectives through torch.distributed | "native" (direct RCCL, csrc/comm.cpp)
+    comm: str = "native"               # GPU collectives: "native" (direct RCCL, csrc/comm.cpp) | "torch" (torch.distributed)
     loss: Optional[str] = None         # xent | l1 (default per workload)
     checkpoint: Optional[str] = None   # path to save to after every epoch
     resume: Optional[str] = None
@@ -105,7 +105,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--sync", choices=list(SYNC_MODES), default="allreduce")
     p.add_argument("--bucket-mb", dest="bucket_mb", type=float, default=32.0)
     p.add_argument("--grad-dtype", dest="grad_dtype", choices=["fp32", "bf16"], default="fp32")
-    p.add_argument("--comm", choices=["torch", "native"], default="torch")
+    p.add_argument("--comm", choices=["torch", "native"], default="native",
+                   help="GPU gradient collectives: native RCCL communicator (default) or torch.distributed; CPU runs use gloo")
     p.add_argument("--loss", choices=["xent", "l1"], default=None)
     p.add_argument("--checkpoint", default=None)
     p.add_argument("--resume", default=None)

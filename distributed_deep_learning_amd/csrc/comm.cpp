@@ -29,6 +29,9 @@ struct Api {
   int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
   int (*Broadcast)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
   int (*GetVersion)(int*) = nullptr;
+  int (*CommCount)(Comm, int*) = nullptr;
+  int (*CommUserRank)(Comm, int*) = nullptr;
+  int (*CommAbort)(Comm) = nullptr;
   bool ok() const { return handle != nullptr; }
 } api;
 
@@ -54,7 +57,9 @@ int ddl_comm_load(const char* path) {
   const bool all = sym(h, "ncclGetUniqueId", a.GetUniqueId) && sym(h, "ncclCommInitRank", a.CommInitRank) &&
                    sym(h, "ncclCommDestroy", a.CommDestroy) && sym(h, "ncclAllReduce", a.AllReduce) &&
                    sym(h, "ncclReduceScatter", a.ReduceScatter) && sym(h, "ncclAllGather", a.AllGather) &&
-                   sym(h, "ncclBroadcast", a.Broadcast) && sym(h, "ncclGetVersion", a.GetVersion);
+                   sym(h, "ncclBroadcast", a.Broadcast) && sym(h, "ncclGetVersion", a.GetVersion) &&
+                   sym(h, "ncclCommCount", a.CommCount) && sym(h, "ncclCommUserRank", a.CommUserRank) &&
+                   sym(h, "ncclCommAbort", a.CommAbort);
   if (!all) return -2;
   api = a;
   return 0;
@@ -91,6 +96,25 @@ int ddl_comm_init(const void* id128, int rank, int world, void** comm_out) {
 int ddl_comm_destroy(void* comm) {
   if (!api.ok() || comm == nullptr) return -1;
   return api.CommDestroy((Comm)comm);
+}
+
+// Tear a communicator down without waiting for outstanding collectives (a rank that gives up on a hung job).
+int ddl_comm_abort(void* comm) {
+  if (!api.ok() || comm == nullptr) return -1;
+  return api.CommAbort((Comm)comm);
+}
+
+// What the communicator itself reports: number of ranks (ncclCommCount) and this rank's index; negative on error.
+int ddl_comm_count(void* comm) {
+  int n = 0;
+  if (!api.ok() || comm == nullptr || api.CommCount((Comm)comm, &n) != 0) return -1;
+  return n;
+}
+
+int ddl_comm_user_rank(void* comm) {
+  int r = 0;
+  if (!api.ok() || comm == nullptr || api.CommUserRank((Comm)comm, &r) != 0) return -1;
+  return r;
 }
 
 // dtype: 0 = fp32, 1 = bf16.  op: 0 = sum, 1 = average.  In place when send == recv.

@@ -81,6 +81,40 @@ def crop_resize(img: torch.Tensor, top: int, left: int, height: int, width: int,
     return out.clamp_(0.0, 255.0)
 
 
+class LazyPCBDataset(torch.utils.data.Dataset):
+    """The PCB-defect dataset decoded PER SAMPLE on access (what the loader's ``-w`` worker threads parallelise):
+    same samples, shifts and targets as :func:`pcb_defects` — which decodes everything once into RAM — for datasets
+    that should not be held decoded in memory.  A small per-thread cache keeps the most recent image, since the two
+    shifted crops of a box (and neighbouring boxes of one photo) are usually fetched together."""
+
+    def __init__(self, root: str = "/data/PCB_DATASET", size: int = 64, seed: int = 0, one_hot: bool = True):
+        import threading
+        self.classes, self.instances = list_pcb_instances(root)
+        g = torch.Generator().manual_seed(seed)
+        self.shifts = torch.randint(5, 11, (2 * len(self.instances),), generator=g).tolist()
+        self.size, self.one_hot = size, one_hot
+        self._local = threading.local()
+
+    def __len__(self) -> int:
+        return 2 * len(self.instances)
+
+    def _image(self, path: str) -> torch.Tensor:
+        from PIL import Image
+        if getattr(self._local, "path", None) != path:
+            with Image.open(path) as im:
+                self._local.img = torch.from_numpy(np.asarray(im.convert("RGB")).copy()).permute(2, 0, 1)
+            self._local.path = path
+        return self._local.img
+
+    def __getitem__(self, i):
+        i = int(i)
+        path, (xmin, ymin, xmax, ymax), ci = self.instances[i >> 1]        # reference: index>>1 picks the box
+        s = self.shifts[i]
+        x = crop_resize(self._image(path), ymin + s, xmin + s, ymax - ymin, xmax - xmin, self.size)
+        y = F.one_hot(torch.tensor(ci), len(self.classes)).float() if self.one_hot else torch.tensor(ci)
+        return x, y
+
+
 def pcb_defects(root: str = "/data/PCB_DATASET", size: int = 64, seed: int = 0, one_hot: bool = True) -> TensorDataset:
     from PIL import Image
 
@@ -140,10 +174,11 @@ def tabular_csv(path: str = "/data/MQTT/dataset.csv", targets: int = 5, drop_fir
     return TensorDataset(data[:, :-targets].contiguous(), data[:, -targets:].contiguous())
 
 
-def open_dataset(kind: str, path: str, seed: int = 0):
-    """``kind``: the workload family (``cnn`` | ``lstm`` | ``mlp``)."""
+def open_dataset(kind: str, path: str, seed: int = 0, lazy: bool = False):
+    """``kind``: the workload family (``cnn`` | ``lstm`` | ``mlp``).  ``lazy`` (set when ``-w N > 0``): the image
+    dataset decodes per sample on access, in the loader's worker threads, instead of once into RAM."""
     if kind in ("cnn", "densenet_ref"):
-        return pcb_defects(path, seed=seed)
+        return LazyPCBDataset(path, seed=seed) if lazy else pcb_defects(path, seed=seed)
     if kind in ("lstm", "lstm_ref"):
         return window_csv(path)
     if kind in ("mlp", "mlp_ref"):

@@ -1,8 +1,19 @@
 """Batch loader: sampler -> index batches -> one gather per batch (device-resident data) or one async H2D per
 batch from pinned memory, prefetched on a side HIP stream.  Replaces the reference's per-sample
-``__getitem__`` + ``.to(device)`` + default collate path (``/root/reference/src/pytorch/CNN/main.py:177-179``)."""
+``__getitem__`` + ``.to(device)`` + default collate path (``/root/reference/src/pytorch/CNN/main.py:177-179``).
+
+``workers`` is the reference's ``-w/--nworkers`` (``main.py:54,177-179``: ``DataLoader(num_workers=N_WORKERS)``): N
+background threads assemble whole batches ahead of the training loop (per-sample decode of a lazy file-backed dataset —
+PIL's decoders and torch's resize release the GIL — then collate into PINNED host memory), at most ``2 * workers``
+batches in flight, delivered in sampler order; the consumer only issues the asynchronous H2D copy.  Threads, not
+processes: nothing has to be pickled or re-opened per worker and pinned buffers are shared with the copy engine
+directly.  Data that already lives on the GPU (the synthetic datasets) is sliced in place; workers would add
+nothing there and are not started.
+"""
 from __future__ import annotations
 
+import concurrent.futures as cf
+from collections import deque
 from typing import Iterator, Optional, Tuple
 
 import torch
@@ -12,12 +23,23 @@ from .sampler import ShardedSampler
 
 class BatchLoader:
     def __init__(self, dataset, sampler: ShardedSampler, batch_size: int, device: Optional[torch.device] = None,
-                 drop_last: bool = False, prefetch: bool = True):
+                 drop_last: bool = False, prefetch: bool = True, workers: int = 0):
         self.dataset, self.sampler, self.batch_size = dataset, sampler, int(batch_size)
         self.device = device
         self.drop_last = drop_last
         self.prefetch = prefetch and device is not None and device.type == "cuda"
         self._stream = torch.cuda.Stream(device) if self.prefetch else None
+        if workers < 0:
+            raise ValueError("workers must be >= 0")
+        self.workers = 0 if self._device_resident() else int(workers)
+        self._pool: Optional[cf.ThreadPoolExecutor] = None
+
+    def _device_resident(self) -> bool:
+        for name in ("x", "data"):
+            t = getattr(self.dataset, name, None)
+            if isinstance(t, torch.Tensor):
+                return t.is_cuda
+        return False
 
     def __len__(self) -> int:
         n = len(self.sampler)
@@ -26,44 +48,92 @@ class BatchLoader:
     def set_epoch(self, epoch: int) -> None:
         self.sampler.set_epoch(epoch)
 
-    def _fetch(self, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    def _assemble(self, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Host part of a batch (runs in a worker thread when ``workers > 0``): gather / decode + collate, pinned when
+        the batch is bound for a GPU."""
         if hasattr(self.dataset, "batch"):
             x, y = self.dataset.batch(idx)
         else:
             items = [self.dataset[int(i)] for i in idx]
             x = torch.stack([a for a, _ in items])
             y = torch.stack([torch.as_tensor(b) for _, b in items])
+        if self.device is not None and self.device.type == "cuda" and not x.is_cuda:
+            x, y = x.pin_memory(), y.pin_memory()
+        return x, y
+
+    def _to_device(self, x, y):
         if self.device is not None and x.device != self.device:
-            if self.device.type == "cuda":
-                x, y = x.pin_memory(), y.pin_memory()
             x = x.to(self.device, non_blocking=True)
             y = y.to(self.device, non_blocking=True)
         return x, y
+
+    def _fetch(self, idx: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return self._to_device(*self._assemble(idx))
+
+    def _host_batches(self, batches):
+        """Assembled host batches in order; with workers, up to ``2 * workers`` are being built ahead."""
+        if self.workers <= 0:
+            for b in batches:
+                yield self._assemble(b)
+            return
+        if self._pool is None:
+            self._pool = cf.ThreadPoolExecutor(max_workers=self.workers, thread_name_prefix="ddl-loader")
+        depth = 2 * self.workers
+        pending: deque = deque()
+        it = iter(batches)
+        try:
+            for b in it:
+                pending.append(self._pool.submit(self._assemble, b))
+                if len(pending) >= depth:
+                    yield pending.popleft().result()
+            while pending:
+                yield pending.popleft().result()
+        finally:
+            for f in pending:
+                f.cancel()
 
     def __iter__(self) -> Iterator[Tuple[torch.Tensor, torch.Tensor]]:
         order = torch.tensor(list(iter(self.sampler)), dtype=torch.int64)
         batches = [order[i:i + self.batch_size] for i in range(0, len(order), self.batch_size)]
         if self.drop_last and batches and len(batches[-1]) < self.batch_size:
             batches.pop()
+        host = self._host_batches(batches)
         if not self.prefetch:
-            for b in batches:
-                yield self._fetch(b)
+            for x, y in host:
+                yield self._to_device(x, y)
             return
         nxt = None
         cur_stream = torch.cuda.current_stream(self.device)
-        for i in range(len(batches) + 1):
+        done = False
+        while True:
             cur = nxt
-            if i < len(batches):
-                with torch.cuda.stream(self._stream):
-                    nxt = self._fetch(batches[i])
-                    ev = torch.cuda.Event()
-                    ev.record(self._stream)
-                    nxt = (*nxt, ev)
-            else:
-                nxt = None
+            nxt = None
+            if not done:
+                try:
+                    hx, hy = next(host)
+                    with torch.cuda.stream(self._stream):
+                        dx, dy = self._to_device(hx, hy)
+                        ev = torch.cuda.Event()
+                        ev.record(self._stream)
+                    nxt = (dx, dy, ev, (hx, hy))           # keep the pinned source alive until the copy was waited for
+                except StopIteration:
+                    done = True
             if cur is not None:
-                x, y, ev = cur
+                x, y, ev, _keep = cur
                 cur_stream.wait_event(ev)
                 x.record_stream(cur_stream)
                 y.record_stream(cur_stream)
                 yield x, y
+            elif done:
+                return
+
+    def close(self) -> None:
+        if self._pool is not None:
+            self._pool.shutdown(wait=False, cancel_futures=True)
+            self._pool = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001 - interpreter shutdown
+            pass

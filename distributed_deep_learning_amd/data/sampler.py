@@ -31,16 +31,25 @@ def split_indices(n: int, fractions: Sequence[float] = (0.7, 0.1, 0.2), seed: in
 
 class ShardedSampler(torch.utils.data.Sampler):
     def __init__(self, indices, rank: int = 0, world: int = 1, shuffle: bool = True, seed: int = 0,
-                 drop_last: bool = False):
+                 drop_last: bool = False, pad: bool = True):
+        """``pad=True`` (training): every rank gets ``ceil(n / world)`` indices, the tail wraps around, so all ranks run
+        the same number of steps (their collectives must pair up).  ``pad=False`` (evaluation): no index is repeated —
+        ranks get ``n // world`` or ``n // world + 1`` indices — so metrics summed over ranks count every sample of
+        the split exactly once."""
         if not (0 <= rank < world):
             raise ValueError(f"rank {rank} outside world {world}")
         self.indices = torch.as_tensor(indices, dtype=torch.int64).clone()
         self.rank, self.world = rank, world
-        self.shuffle, self.seed, self.drop_last = shuffle, int(seed), drop_last
+        self.shuffle, self.seed, self.drop_last, self.pad = shuffle, int(seed), drop_last, bool(pad)
         self.epoch = 0
         n = len(self.indices)
-        self.num_samples = n // world if drop_last else math.ceil(n / world)
-        self.total = self.num_samples * world
+        if drop_last:
+            self.num_samples = n // world
+        elif self.pad:
+            self.num_samples = math.ceil(n / world)
+        else:
+            self.num_samples = n // world + (1 if rank < n % world else 0)
+        self.total = n if (not drop_last and not self.pad) else self.num_samples * world
 
     def set_epoch(self, epoch: int) -> None:
         self.epoch = int(epoch)

@@ -63,6 +63,9 @@ _SIGS = {
     "ddl_comm_unique_id": [_vp],
     "ddl_comm_init": [_vp, _i, _i, _vp],
     "ddl_comm_destroy": [_vp],
+    "ddl_comm_abort": [_vp],
+    "ddl_comm_count": [_vp],
+    "ddl_comm_user_rank": [_vp],
     "ddl_comm_all_reduce": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "ddl_comm_reduce_scatter": [_vp, _vp, _vp, _ll, _i, _i, _vp],
     "ddl_comm_all_gather": [_vp, _vp, _vp, _ll, _i, _vp],
@@ -116,6 +119,44 @@ def stream_ptr() -> int:
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class WrongDeviceError(RuntimeError):
+    pass
+
+
+def check_device(t: torch.Tensor, what: str = "kernel") -> None:
+    """Every wrapper launches on the CURRENT device's current stream (``stream_ptr``): an operand that lives on
+    another GPU would be processed by the wrong device, unordered against the ATen work on its own stream.  Callers
+    that span devices (model / pipeline parallelism, per-stage optimizers) wrap their work in :func:`device_of`."""
+    if t.is_cuda and _cur_device is not None and t.device.index != _cur_device():
+        raise WrongDeviceError(f"{what}: operand on cuda:{t.device.index} but the current device is cuda:{_cur_device()} "
+                               "(wrap the call in ops._lib.device_of(tensor))")
+
+
+class device_of:
+    """``with device_of(t): ...`` — make ``t``'s GPU the current device for the block (a no-op for CPU tensors and
+    when it already is current, so the single-GPU hot path pays one integer compare)."""
+
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, t):
+        dev = t if isinstance(t, torch.device) else getattr(t, "device", None)
+        self.idx = dev.index if (dev is not None and dev.type == "cuda") else None
+        self.prev = None
+
+    def __enter__(self):
+        if self.idx is not None and _cur_device is not None:
+            cur = _cur_device()
+            if cur != self.idx:
+                self.prev = cur
+                torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False
 
 
 def ptr(t):

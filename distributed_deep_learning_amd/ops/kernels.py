@@ -29,6 +29,7 @@ def nhwc(x: torch.Tensor) -> torch.Tensor:
 def _chk_act(x: torch.Tensor, name: str) -> None:
     if not x.is_cuda or x.dtype != BF16:
         raise TypeError(f"{name}: expected a bf16 GPU tensor, got {x.dtype} on {x.device}")
+    _lib.check_device(x, name)              # launches go to the CURRENT device's stream (ops/_lib.py)
 
 
 def conv_out_size(h: int, k: int, stride: int, pad: int) -> int:
@@ -506,6 +507,15 @@ def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor | None = None):
     if dst is None:
         dst = torch.empty(src.shape, dtype=BF16, device=src.device)
     check(lib.ddl_cast_f32_bf16(ptr(src), ptr(dst), n, stream_ptr()), "cast_f32_bf16")
+    return dst
+
+
+def cast_bf16_f32(src: torch.Tensor, dst: torch.Tensor | None = None):
+    lib = _lib.require()
+    n = src.numel()
+    if dst is None:
+        dst = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    check(lib.ddl_cast_bf16_f32(ptr(src), ptr(dst), n, stream_ptr()), "cast_bf16_f32")
     return dst
 
 

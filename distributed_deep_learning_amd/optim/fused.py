@@ -62,6 +62,8 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         self._seg_wd_host = seg_wd
         self._seg_adapt_host = seg_adapt
         self.flat_state = {k: torch.zeros(arena.total, dtype=torch.float32, device=dev) for k in self._state_names}
+        self._shard: Optional[List] = None      # PS / ZeRO-1: [(lo, hi, compact offset)] once shard_state() ran
+        self._gather_state: Optional[Callable] = None
         self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
         self._hyper_host = None
         self.grad_scale = 1.0
@@ -94,6 +96,48 @@ class _ArenaOptimizer(torch.optim.Optimizer):
             v[s.offset:s.offset + s.numel] = float(seg_values[s.index])
         return v.to(a.device)
 
+    # ---- sharded state (PS / ZeRO-1 mode): buffers cover only the element ranges this rank updates
+    def shard_state(self, ranges, gather: Optional[Callable] = None) -> None:
+        """Keep optimizer state only for ``ranges`` (the rank's shard of every bucket, chunk aligned): each state
+        tensor shrinks from ``arena.total`` to ``sum(hi - lo)`` elements, the owned ranges back to back.  ``gather``:
+        collective callable (compact tensor -> full arena-layout tensor) used by :meth:`state_dict`."""
+        shard, off = [], 0
+        for lo, hi in ranges:
+            if lo % CHUNK or hi % CHUNK:
+                raise ValueError("optimizer ranges must be chunk aligned")
+            shard.append((lo, hi, off))
+            off += hi - lo
+        old, old_shard = self.flat_state, self._shard
+        new = {k: torch.zeros(off, dtype=torch.float32, device=self.arena.device) for k in self._state_names}
+        for k in self._state_names:
+            for lo, hi, coff in shard:
+                if old_shard is None:
+                    new[k][coff:coff + hi - lo].copy_(old[k][lo:hi])
+        self.flat_state, self._shard, self._gather_state = new, shard, gather
+
+    def _state_base(self, name: str, lo: int) -> int:
+        """Device address the kernels index with ABSOLUTE arena offsets so that element ``lo`` lands on this range's
+        slot of the (possibly compact) state buffer; only addresses inside the buffer are ever dereferenced."""
+        buf = self.flat_state[name]
+        if self._shard is None:
+            return buf.data_ptr()
+        for slo, shi, coff in self._shard:
+            if slo <= lo < shi:
+                return buf.data_ptr() + 4 * (coff - slo)
+        raise ValueError(f"optimizer state is sharded and holds nothing for element {lo}")
+
+    def _state_slice(self, name: str, lo: int, hi: int) -> torch.Tensor:
+        buf = self.flat_state[name]
+        if self._shard is None:
+            return buf[lo:hi]
+        for slo, shi, coff in self._shard:
+            if slo <= lo and hi <= shi:
+                return buf[coff + lo - slo:coff + hi - slo]
+        raise ValueError(f"optimizer state is sharded and holds nothing for [{lo}, {hi})")
+
+    def state_bytes(self) -> int:
+        return sum(v.numel() * v.element_size() for v in self.flat_state.values())
+
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: D401 - torch signature
         """Gradients live in the arena; clearing is one memset (and the fused step already does it)."""
         self.arena.zero_grad()
@@ -104,10 +148,11 @@ class _ArenaOptimizer(torch.optim.Optimizer):
     def step(self, closure=None, ranges=None, zero_grad: bool = True):
         """``ranges``: optional list of element ranges ``(lo, hi)`` (PS mode); default = whole arena."""
         loss = closure() if closure is not None else None
-        _streams.join()                 # side-stream filter gradients must have landed in the arena
-        self.host_prepare()
-        self.launch(ranges, zero_grad)
-        self.host_finish()
+        with _lib.device_of(self.arena.device):     # per-stage optimizers (model parallel): launch on the arena's GPU
+            _streams.join()             # side-stream filter gradients must have landed in the arena
+            self.host_prepare()
+            self.launch(ranges, zero_grad)
+            self.host_finish()
         return loss
 
     # The step in three parts, so a captured HIP graph (utils/graph.py) can hold ONLY the device part: the host
@@ -142,10 +187,18 @@ class _ArenaOptimizer(torch.optim.Optimizer):
 
     # ---- (de)serialisation: flat state + scalars
     def state_dict(self):
+        """Full (un-sharded) flat state in arena layout.  With sharded state this is a COLLECTIVE: every rank calls it
+        and every rank gets the complete state (the shards are all-gathered through the reducer)."""
+        if self._shard is not None:
+            if self._gather_state is None:
+                raise RuntimeError("sharded optimizer state needs the reducer's gather to be serialised")
+            flat = {k: self._gather_state(v.detach()).cpu() for k, v in self.flat_state.items()}
+        else:
+            flat = {k: v.detach().cpu().clone() for k, v in self.flat_state.items()}
         return {
             "kind": type(self).__name__,
             "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups],
-            "flat_state": {k: v.detach().cpu().clone() for k, v in self.flat_state.items()},
+            "flat_state": flat,
             "step_count": self.step_count,
             "layout": [(s.name, s.offset, s.numel) for s in self.arena.segments],
         }
@@ -158,11 +211,13 @@ class _ArenaOptimizer(torch.optim.Optimizer):
         for g, sg in zip(self.param_groups, sd["param_groups"]):
             g.update(sg)
         self.step_count = int(sd["step_count"])
+        full = {}
         if saved == layout:
-            for k, v in sd["flat_state"].items():
-                self.flat_state[k].copy_(v)
+            full = dict(sd["flat_state"])
         else:  # different bucket plan / world size: remap tensor by tensor
             by_name = {n: (o, c) for n, o, c in saved}
+            for k, v in sd["flat_state"].items():
+                full[k] = torch.zeros(self.arena.total, dtype=torch.float32)
             for s in self.arena.segments:
                 if s.name not in by_name:
                     raise KeyError(f"optimizer state for {s.name} missing from checkpoint")
@@ -170,7 +225,13 @@ class _ArenaOptimizer(torch.optim.Optimizer):
                 if c != s.numel:
                     raise ValueError(f"optimizer state size mismatch for {s.name}")
                 for k, v in sd["flat_state"].items():
-                    self.flat_state[k][s.offset:s.offset + c].copy_(v[o:o + c])
+                    full[k][s.offset:s.offset + c].copy_(v[o:o + c])
+        for k, v in full.items():
+            if self._shard is None:
+                self.flat_state[k].copy_(v)
+            else:                                   # sharded: every rank keeps its own ranges of the full state
+                for lo, hi, coff in self._shard:
+                    self.flat_state[k][coff:coff + hi - lo].copy_(v[lo:hi])
         self._hyper_host = None
 
 
@@ -237,11 +298,11 @@ class FusedSGD(_ArenaOptimizer):
     def _update(self, clo: int, chi: int, zero_grad: bool) -> None:
         g = self.param_groups[0]
         a = self.arena
-        mom = self.flat_state["momentum"]
         use_mom = g["momentum"] != 0.0
         if self._use_kernel():
             lib = _lib.require()
-            _lib.check(lib.ddl_flat_sgd(a.master.data_ptr(), a.grad.data_ptr(), mom.data_ptr() if use_mom else None,
+            _lib.check(lib.ddl_flat_sgd(a.master.data_ptr(), a.grad.data_ptr(),
+                                        self._state_base("momentum", clo * CHUNK) if use_mom else None,
                                         a.shadow.data_ptr() if a.shadow is not None else None,
                                         a.chunk_seg.data_ptr(), self.seg_wd.data_ptr(), self.seg_adapt.data_ptr(),
                                         self.norms.data_ptr() if g["lars"] else None, self.hyper.data_ptr(),
@@ -259,7 +320,7 @@ class FusedSGD(_ArenaOptimizer):
             trust = torch.where((wn > 0) & (gn > 0) & (self.seg_adapt > 0), trust, torch.ones_like(trust))
             gp = gp * self._elem_vec(trust.cpu())[lo:hi]
         if use_mom:
-            m = mom[lo:hi]
+            m = self._state_slice("momentum", lo, hi)
             m.mul_(g["momentum"]).add_(gp, alpha=1.0 - g["dampening"])
             stepv = gp + g["momentum"] * m if g["nesterov"] else m
         else:
@@ -297,10 +358,11 @@ class FusedAdam(_ArenaOptimizer):
     def _update(self, clo: int, chi: int, zero_grad: bool) -> None:
         g = self.param_groups[0]
         a = self.arena
-        m, v = self.flat_state["exp_avg"], self.flat_state["exp_avg_sq"]
         if self._use_kernel():
             lib = _lib.require()
-            _lib.check(lib.ddl_flat_adam(a.master.data_ptr(), a.grad.data_ptr(), m.data_ptr(), v.data_ptr(),
+            _lib.check(lib.ddl_flat_adam(a.master.data_ptr(), a.grad.data_ptr(),
+                                         self._state_base("exp_avg", clo * CHUNK),
+                                         self._state_base("exp_avg_sq", clo * CHUNK),
                                          a.shadow.data_ptr() if a.shadow is not None else None,
                                          a.chunk_seg.data_ptr(), self.seg_wd.data_ptr(), self.hyper.data_ptr(), clo,
                                          chi, int(zero_grad), _lib.stream_ptr()), "flat_adam")
@@ -312,10 +374,11 @@ class FusedAdam(_ArenaOptimizer):
         if self._wd_vec is None:
             self._wd_vec = self._elem_vec(self._seg_wd_host)
         gp = gr * self.grad_scale + self._wd_vec[lo:hi] * w
-        m[lo:hi].mul_(b1).add_(gp, alpha=1 - b1)
-        v[lo:hi].mul_(b2).addcmul_(gp, gp, value=1 - b2)
-        denom = (v[lo:hi] / (1 - b2 ** t)).sqrt_().add_(g["eps"])
-        w.addcdiv_(m[lo:hi] / (1 - b1 ** t), denom, value=-g["lr"])
+        m, v = self._state_slice("exp_avg", lo, hi), self._state_slice("exp_avg_sq", lo, hi)
+        m.mul_(b1).add_(gp, alpha=1 - b1)
+        v.mul_(b2).addcmul_(gp, gp, value=1 - b2)
+        denom = (v / (1 - b2 ** t)).sqrt_().add_(g["eps"])
+        w.addcdiv_(m / (1 - b1 ** t), denom, value=-g["lr"])
         if a.shadow is not None:
             a.shadow[lo:hi].copy_(w)
         if zero_grad:

@@ -217,12 +217,13 @@ class ParamArena:
     def sync_shadow(self) -> None:
         """Refresh the bf16 shadow from the fp32 master (after init, broadcast, load_state_dict, all-gather)."""
         if self.shadow is not None:
-            if self.device.type == "cuda" and _lib.available():
-                from ..ops import kernels as K
-                K.cast_f32_bf16(self.master, self.shadow)
-            else:
-                self.shadow.copy_(self.master)
-            self.refresh_transposes()
+            with _lib.device_of(self.device):
+                if self.device.type == "cuda" and _lib.available():
+                    from ..ops import kernels as K
+                    K.cast_f32_bf16(self.master, self.shadow)
+                else:
+                    self.shadow.copy_(self.master)
+                self.refresh_transposes()
         self.mark_shadow_current()
 
     def mark_shadow_current(self) -> None:

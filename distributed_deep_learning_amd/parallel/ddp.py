@@ -3,18 +3,29 @@
 Two sync modes behind one wrapper:
 
 ``allreduce``  every gradient bucket (a contiguous arena range) is all-reduced IN PLACE as soon as all of its
-               tensors have their gradients, overlapping with the rest of backward on RCCL's own stream.
+               tensors have their gradients, overlapping with the rest of backward on the communicator's stream.
 ``ps``         parameter-server style (ZeRO-1): each bucket is reduce-scattered, every rank updates only the
-               shard it owns (fused SGD/LARS over that range) and the updated fp32 masters are all-gathered.
-               Same result as ``allreduce`` with 1/N of the optimizer work and state traffic per GPU.
+               shard it owns and the updated parameters are all-gathered — :class:`.ps.ShardedDataParallel`
+               (``DistributedDataParallel(mode="ps")`` constructs that subclass).
 
 Design notes for MI355X: xGMI is point-to-point (7 links x ~153 GB/s), ring collectives are per-link bound, so
 buckets are few and large (default 32 MiB; small models collapse to 1-2) — but the LAST bucket (first ready in
-backward) is small so communication starts early.  No pack/unpack kernels: buckets ARE arena ranges.  Collectives
-are issued in a fixed bucket order on every rank (bucket i only after i+1), so ranks can never deadlock on
-mismatched call order even if autograd visits parameters differently.
+backward) is small so communication starts early.  No pack/unpack kernels for the default fp32 wire format: buckets
+ARE arena ranges.  Collectives are issued in a fixed bucket order on every rank (bucket i only after i+1), so ranks
+can never deadlock on mismatched call order even if autograd visits parameters differently.
 
-Works on gloo (CPU tensors) with the same code path: the reducer logic is proven by multi-process CPU tests.
+Transports (one reducer, three ways to move a bucket):
+
+* GPU, ``comm="native"`` (default): direct RCCL calls from ``csrc/comm.cpp`` on a stream the communicator owns;
+  checked once against ``torch.distributed`` at start-up (all ranks agree to fall back together if it disagrees);
+* GPU, ``comm="torch"``: ``torch.distributed`` (backend ``nccl`` = RCCL);
+* gloo: CPU tensors directly; GPU tensors are staged through pinned host memory BY THIS MODULE (gloo's own
+  GPU path runs its copies on high-priority streams that wait on events of normal-priority streams — the pattern
+  behind the two GPU-side deadlocks recorded in ``docs/STATUS.md``; the staging here uses only the current stream).
+
+A watchdog thread follows one HIP event per step: a step whose collectives have not finished after
+``watchdog_s`` seconds is reported (bucket ids, pending counts, launch order, which collectives completed) and the
+process exits non-zero instead of hanging the job.
 
 Reference behaviour replaced: per-parameter blocking ``all_reduce`` + divide after backward
 (``/root/reference/src/pytorch/CNN/main.py:136-139``), which in spawn mode is never even installed (``:133-142``)
@@ -23,6 +34,12 @@ broadcast (``main.py:132``).
 """
 from __future__ import annotations
 
+import collections
+import datetime
+import os
+import sys
+import threading
+import time
 from typing import List, Optional
 
 import torch
@@ -30,22 +47,112 @@ import torch.distributed as td
 import torch.nn as tnn
 
 from ..ops import streams
+from ..ops._lib import device_of
 from .arena import ParamArena
 
 
+class ReducerWatchdog:
+    """Turns a hung gradient collective into a report and a non-zero exit.
+
+    ``note(tag, probe)``: ``probe()`` returns True once the work behind ``tag`` has finished (a HIP event query or a
+    c10d work's ``is_completed``).  A daemon thread retires finished entries in order; the oldest unfinished one
+    older than ``timeout_s`` triggers ``report(tag, age)`` (text for stderr) and ``os._exit(exit_code)``."""
+
+    def __init__(self, timeout_s: float, report, exit_code: int = 3, on_timeout=None):
+        self.timeout_s = float(timeout_s)
+        self.report = report
+        self.exit_code = exit_code
+        self.on_timeout = on_timeout            # tests: called instead of exiting
+        self._q: collections.deque = collections.deque()
+        self._lock = threading.Lock()
+        self._stop = threading.Event()
+        self._thread: Optional[threading.Thread] = None
+        self.fired = False
+
+    def note(self, tag, probe) -> None:
+        if self.timeout_s <= 0:
+            return
+        with self._lock:
+            self._q.append((time.monotonic(), tag, probe))
+            if len(self._q) > 64:               # never grows without bound when steps outrun the poll interval
+                while len(self._q) > 1 and self._safe(self._q[0][2]):
+                    self._q.popleft()
+        if self._thread is None:
+            self._thread = threading.Thread(target=self._run, name="ddl-reducer-watchdog", daemon=True)
+            self._thread.start()
+
+    @staticmethod
+    def _safe(probe) -> bool:
+        try:
+            return bool(probe())
+        except Exception:                       # noqa: BLE001 - a failing probe must not kill the watchdog
+            return False
+
+    def _run(self) -> None:
+        poll = min(1.0, max(0.02, self.timeout_s / 20.0))
+        while not self._stop.wait(poll):
+            with self._lock:
+                while self._q and self._safe(self._q[0][2]):
+                    self._q.popleft()
+                head = self._q[0] if self._q else None
+            if head is not None and time.monotonic() - head[0] > self.timeout_s:
+                self.fired = True
+                age = time.monotonic() - head[0]
+                try:
+                    text = self.report(head[1], age)
+                except Exception as e:          # noqa: BLE001
+                    text = f"(report failed: {e!r})"
+                print(text, file=sys.stderr, flush=True)
+                if self.on_timeout is not None:
+                    self.on_timeout(head[1], age)
+                    with self._lock:
+                        self._q.clear()
+                    continue
+                os._exit(self.exit_code)
+
+    def stop(self) -> None:
+        self._stop.set()
+
+
+class _HostStagedWork:
+    """gloo collective on a GPU tensor, staged through pinned host memory on the current stream."""
+
+    def __init__(self, work, host: torch.Tensor, dev: torch.Tensor):
+        self.work, self.host, self.dev = work, host, dev
+
+    def is_completed(self) -> bool:
+        return self.work.is_completed()
+
+    def wait(self, timeout=None) -> None:
+        if timeout is not None:
+            self.work.wait(timeout)
+        else:
+            self.work.wait()
+        self.dev.copy_(self.host, non_blocking=True)
+
+
 class DistributedDataParallel(tnn.Module):
+    def __new__(cls, *args, **kwargs):
+        mode = kwargs.get("mode", args[2] if len(args) > 2 else "allreduce")
+        if cls is DistributedDataParallel and mode == "ps":
+            from .ps import ShardedDataParallel
+            return super().__new__(ShardedDataParallel)
+        return super().__new__(cls)
+
     def __init__(self, module: tnn.Module, bucket_mb: float = 32.0, mode: str = "allreduce",
                  arena: Optional[ParamArena] = None, process_group=None, broadcast_buffers: bool = True,
                  first_bucket_mb: Optional[float] = None, force_collectives: bool = False,
-                 grad_dtype: Optional[torch.dtype] = None, comm: str = "torch"):
+                 grad_dtype: Optional[torch.dtype] = None, comm: Optional[str] = None,
+                 watchdog_s: Optional[float] = None):
         """``force_collectives``: issue the (identity) collectives even with a world size of 1 — lets a one-GPU box
         drive the real RCCL path (async works, comm-stream ordering, reduce-scatter / all-gather shapes).
-        ``grad_dtype=torch.bfloat16``: gradients travel in bf16 (each bucket is packed into a persistent bf16 buffer,
-        reduced, unpacked into the fp32 arena) — half the xGMI bytes for bandwidth-bound models such as VGG-16
-        (553 MB of fp32 gradients per step); the default reduces the fp32 arena in place, with no copies.
-        ``comm="native"``: gradient / parameter collectives go through :class:`.native_comm.NativeCommunicator` (direct
-        RCCL calls from ``csrc/comm.cpp`` on its own stream) instead of ``torch.distributed``, which then only
-        bootstraps (unique-id exchange, initial broadcast).  GPU only."""
+        ``grad_dtype=torch.bfloat16``: gradients travel in bf16 (each bucket is packed into a persistent bf16 buffer by
+        the cast kernel, reduced, unpacked into the fp32 arena) — half the xGMI bytes for bandwidth-bound models such
+        as VGG-16 (553 MB of fp32 gradients per step); the default reduces the fp32 arena in place, with no copies.
+        ``comm``: ``"native"`` (GPU default) = :class:`.native_comm.NativeCommunicator`, direct RCCL calls on its own
+        stream with ``torch.distributed`` as bootstrap only; ``"torch"`` = ``torch.distributed`` collectives.
+        ``watchdog_s``: seconds before a pending step's collectives are declared hung (0 disables; default 300 or
+        ``DDL_REDUCER_WATCHDOG_S``)."""
         super().__init__()
         if mode not in ("allreduce", "ps"):
             raise ValueError("mode must be 'allreduce' or 'ps'")
@@ -64,18 +171,22 @@ class DistributedDataParallel(tnn.Module):
             raise ValueError("PS mode needs an arena built with shard_multiple = world size")
         self.arena = arena
         self.backend = td.get_backend(self.pg) if self.dist else "none"
+        self.on_gpu = arena.device.type == "cuda"
+        self.staged = self.backend == "gloo" and self.on_gpu       # gloo over GPU tensors: host staging (see module doc)
         if grad_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be None / torch.float32 (in place) or torch.bfloat16")
         self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None
         self._comm_bufs: dict = {}
+        if comm is None:
+            comm = "native" if (self.on_gpu and self.backend == "nccl") else "torch"
         if comm not in ("torch", "native"):
             raise ValueError("comm must be 'torch' or 'native'")
         self.ncomm = None
+        self.comm_note: Optional[str] = None
         if comm == "native" and self.dist:
-            if arena.device.type != "cuda":
+            if not self.on_gpu:
                 raise ValueError("comm='native' drives RCCL directly: GPU tensors only")
-            from .native_comm import NativeCommunicator
-            self.ncomm = NativeCommunicator(self.rank, self.world, arena.device, group=self.pg)
+            self._open_native()
         self.broadcast_buffers = broadcast_buffers
         self._handles: List = []
         self._pending = [0] * len(arena.buckets)
@@ -84,8 +195,13 @@ class DistributedDataParallel(tnn.Module):
         self.on_synced = None              # debug hook: called by step() once every bucket's collective has finished
         self._next_bucket = len(arena.buckets) - 1
         self._launched = [False] * len(arena.buckets)
+        self._launch_order: List[int] = []
         self._armed = False
+        self._steps = 0
         self.require_sync = True
+        if watchdog_s is None:
+            watchdog_s = float(os.environ.get("DDL_REDUCER_WATCHDOG_S", "300"))
+        self.watchdog = ReducerWatchdog(watchdog_s, self._hang_report) if self.dist else None
         self.sync_parameters()
         self._hooks = []
         if self.dist:
@@ -94,16 +210,79 @@ class DistributedDataParallel(tnn.Module):
             # kernels that accumulate straight into the arena gradient report readiness through the arena
             arena.on_grad_ready = lambda seg: self._segment_ready(seg)
 
+    # ------------------------------------------------------------------ transports
+    def _open_native(self) -> None:
+        """Create the native communicator and compare one averaged all-reduce with ``torch.distributed``'s; every rank
+        learns the verdict of all ranks, so a failed check moves the WHOLE job to ``comm='torch'``."""
+        from .native_comm import NativeCommunicator
+        ok = 1.0
+        try:
+            self.ncomm = NativeCommunicator(self.rank, self.world, self.arena.device, group=self.pg)
+            t = torch.arange(4096, dtype=torch.float32, device=self.arena.device) * float(self.rank + 1) + 0.25
+            ref = t.clone()
+            self.ncomm.all_reduce(t, average=True).wait()
+            td.all_reduce(ref, op=td.ReduceOp.AVG if self.backend == "nccl" else td.ReduceOp.SUM, group=self.pg)
+            if self.backend != "nccl":
+                ref /= self.world
+            if not torch.allclose(t, ref, rtol=1e-6, atol=1e-6) or self.ncomm.ranks() != self.world:
+                ok = 0.0
+        except Exception as e:                  # noqa: BLE001 - any failure of the optional transport means fallback
+            ok = 0.0
+            self.comm_note = f"native communicator unavailable on rank {self.rank}: {e!r}"
+        flag = torch.tensor([ok], device=self.arena.device if self.backend == "nccl" else "cpu")
+        td.all_reduce(flag, op=td.ReduceOp.MIN, group=self.pg)
+        if float(flag.item()) < 1.0:
+            if self.ncomm is not None:
+                self.ncomm.close()
+            self.ncomm = None
+            self.comm_note = (self.comm_note or "native communicator failed its start-up check on some rank") + \
+                "; collectives go through torch.distributed"
+            if self.rank == 0:
+                print(f"[ddp] {self.comm_note}", file=sys.stderr, flush=True)
+
+    def comm_ranks(self) -> int:
+        """Number of ranks the communicator that moves the gradients reports (ncclCommCount / c10d world size)."""
+        if self.ncomm is not None:
+            return self.ncomm.ranks()
+        return self.world
+
+    def _host_buf(self, key, numel: int, dtype) -> torch.Tensor:
+        buf = self._comm_bufs.get(("host", key))
+        if buf is None or buf.numel() != numel or buf.dtype != dtype:
+            buf = torch.empty(numel, dtype=dtype, pin_memory=True)
+            self._comm_bufs[("host", key)] = buf
+        return buf
+
+    def _all_reduce_sum_async(self, t: torch.Tensor, key):
+        """SUM all-reduce through ``torch.distributed`` (async).  gloo + GPU tensor: staged through pinned memory on the
+        current stream (blocks the host until the bucket's producers have finished — rehearsal transport only)."""
+        if self.staged and t.is_cuda:
+            host = self._host_buf(key, t.numel(), t.dtype)
+            host.copy_(t, non_blocking=True)
+            torch.cuda.current_stream(t.device).synchronize()
+            return _HostStagedWork(td.all_reduce(host, op=td.ReduceOp.SUM, group=self.pg, async_op=True), host, t)
+        return td.all_reduce(t, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
+
+    def _broadcast(self, t: torch.Tensor, src: int = 0) -> None:
+        if self.ncomm is not None and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.numel() > 0:
+            self.ncomm.broadcast(t, src).wait()
+        elif self.staged and t.is_cuda:
+            host = t.detach().cpu()
+            td.broadcast(host, src, group=self.pg)
+            t.copy_(host)
+        else:
+            td.broadcast(t, src, group=self.pg)
+
     # ------------------------------------------------------------------ setup
     def sync_parameters(self) -> None:
         """Broadcast rank 0's parameters and buffers (the reference relies on equal seeds only)."""
         if not self.dist:
             return
-        td.broadcast(self.arena.master, 0, group=self.pg)
+        self._broadcast(self.arena.master, 0)
         self.arena.sync_shadow()
         if self.broadcast_buffers:
             for b in self.module.buffers():
-                td.broadcast(b, 0, group=self.pg)
+                self._broadcast(b, 0)
 
     def forward(self, *args, **kwargs):
         self._arm()
@@ -117,6 +296,7 @@ class DistributedDataParallel(tnn.Module):
             self._seen[i] = False
         self._next_bucket = len(self.arena.buckets) - 1
         self._handles = []
+        self._launch_order = []
         self._armed = True
 
     # ------------------------------------------------------------------ hooks
@@ -145,8 +325,9 @@ class DistributedDataParallel(tnn.Module):
         if self._launched[b]:
             return
         self._launched[b] = True
+        self._launch_order.append(b)
         g = self.arena.bucket_grad(b)
-        with streams.comm_context(g):       # ordered behind the side-stream wgrads that wrote into this bucket
+        with device_of(g), streams.comm_context(g):   # ordered behind the side-stream wgrads that wrote into this bucket
             self._launch_collective(b, g)
 
     def _comm_buf(self, key, numel: int) -> torch.Tensor:
@@ -156,44 +337,57 @@ class DistributedDataParallel(tnn.Module):
             self._comm_bufs[key] = buf
         return buf
 
-    def _launch_collective(self, b: int, g: torch.Tensor) -> None:
-        """Enqueue the bucket's collective; ``_handles`` gets ``(work, finish)`` where ``finish()`` (run after the wait,
-        on the current stream) unpacks a compressed buffer and / or applies the 1/world scale gloo cannot fuse."""
-        inv = 1.0 / self.world
-        nccl = self.backend == "nccl"
-        src = g
-        if self.grad_dtype is not None:
-            src = self._comm_buf(("bucket", b), g.numel())
-            src.copy_(g)                                             # pack: fp32 arena -> bf16 wire format
-        if self.mode == "allreduce":
-            if self.ncomm is not None:
-                h = self.ncomm.all_reduce(src, average=True)
-            else:
-                h = td.all_reduce(src, op=td.ReduceOp.AVG if nccl else td.ReduceOp.SUM, group=self.pg, async_op=True)
-            dst, part = g, src
+    def _pack(self, b: int, g: torch.Tensor) -> torch.Tensor:
+        """fp32 arena range -> persistent bf16 wire buffer (one cast kernel of ``csrc/eltwise.hip`` on the GPU)."""
+        src = self._comm_buf(("bucket", b), g.numel())
+        if g.is_cuda:
+            from ..ops import kernels as K
+            K.cast_f32_bf16(g, src)
         else:
-            lo, hi = self.arena.shard_range(b, self.rank, self.world)
-            dst = self.arena.grad[lo:hi]
-            off = lo - self.arena.buckets[b].lo
-            if self.ncomm is not None:
-                part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
-                h = self.ncomm.reduce_scatter(part, src, average=True)
-            elif nccl:
-                part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
-                h = td.reduce_scatter_tensor(part, src, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
-            else:   # gloo has no reduce-scatter: same semantics via all-reduce, only the owned shard is used
-                h = td.all_reduce(src, op=td.ReduceOp.SUM, group=self.pg, async_op=True)
-                part = src[off:off + (hi - lo)]
+            src.copy_(g)
+        return src
 
-        def finish(dst=dst, part=part, scale=not nccl):
+    @staticmethod
+    def _unpack(dst: torch.Tensor, part: torch.Tensor) -> None:
+        if dst.is_cuda and part.dtype == torch.bfloat16 and dst.dtype == torch.float32:
+            from ..ops import kernels as K
+            K.cast_bf16_f32(part, dst)
+        else:
+            dst.copy_(part)
+
+    def _launch_collective(self, b: int, g: torch.Tensor) -> None:
+        """Enqueue the bucket's all-reduce; ``_handles`` gets ``(bucket, work, finish)`` where ``finish()`` (run after
+        the wait, on the current stream) unpacks a compressed buffer and / or applies the 1/world scale gloo cannot
+        fuse."""
+        inv = 1.0 / self.world
+        src = g if self.grad_dtype is None else self._pack(b, g)
+        if self.ncomm is not None:
+            h, scale = self.ncomm.all_reduce(src, average=True), False
+        elif self.backend == "nccl":
+            h, scale = td.all_reduce(src, op=td.ReduceOp.AVG, group=self.pg, async_op=True), False
+        else:
+            h, scale = self._all_reduce_sum_async(src, ("bucket", b)), True
+
+        def finish(dst=g, part=src, scale=scale):
             if part.data_ptr() != dst.data_ptr() or part.dtype != dst.dtype:
-                dst.copy_(part)                                      # unpack (and / or pick the owned shard)
+                self._unpack(dst, part)
             if scale:
                 dst.mul_(inv)
 
-        self._handles.append((h, finish))
+        self._handles.append((b, h, finish))
 
     # ------------------------------------------------------------------ step boundary
+    def _wait(self, b: int, h) -> None:
+        """Order the current stream behind the collective (host-blocking only for gloo, then with a deadline)."""
+        if self.ncomm is not None or self.backend == "nccl" or self.watchdog is None or self.watchdog.timeout_s <= 0:
+            h.wait()
+            return
+        try:
+            h.wait(datetime.timedelta(seconds=self.watchdog.timeout_s))
+        except RuntimeError as e:
+            print(self._hang_report((self._steps, b), self.watchdog.timeout_s), file=sys.stderr, flush=True)
+            raise RuntimeError(f"gradient collective of bucket {b} did not finish: {e}") from e
+
     def finish_grad_sync(self) -> None:
         """Wait for every bucket (launching those whose tensors never produced a gradient)."""
         streams.join()
@@ -205,55 +399,66 @@ class DistributedDataParallel(tnn.Module):
         for b in range(len(self.arena.buckets)):
             self._pending[b] = 0
         self._drain()
-        for h, finish in self._handles:
-            h.wait()
-            finish()
+        with device_of(self.arena.device):
+            for b, h, finish in self._handles:
+                self._wait(b, h)
+                finish()
+            self._note_step()
         self._handles = []
         self._armed = False
 
+    def _note_step(self) -> None:
+        """Hand the watchdog one event behind this step's collectives (GPU transports; not while capturing)."""
+        self._steps += 1
+        wd = self.watchdog
+        if wd is None or wd.timeout_s <= 0 or not self.on_gpu or self.staged:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.arena.device))
+        probes = [(b, getattr(h, "event", None)) for b, h, _ in self._handles]
+        self._last_probes = probes
+        wd.note((self._steps, list(self._launch_order)), ev.query)
+
+    def _hang_report(self, tag, age: float) -> str:
+        step, order = tag if isinstance(tag, tuple) and len(tag) == 2 else (tag, None)
+        lines = [f"[ddl reducer watchdog] rank {self.rank}/{self.world}: collectives of step {step} still pending after "
+                 f"{age:.0f} s (transport: {'native RCCL' if self.ncomm is not None else self.backend}"
+                 f"{', host-staged' if self.staged else ''})",
+                 f"  bucket launch order this step: {order if order is not None else self._launch_order}",
+                 f"  per-bucket pending gradient counts: {list(self._pending)}",
+                 f"  launched: {list(self._launched)}"]
+        done = []
+        for b, ev in getattr(self, "_last_probes", []):
+            try:
+                done.append((b, bool(ev.query()) if ev is not None else None))
+            except Exception:                   # noqa: BLE001
+                done.append((b, None))
+        if done:
+            lines.append(f"  collective finished per bucket (None = not observable): {done}")
+        lines.append("  every rank prints its own view; the rank whose launch order or pending counts differ is the culprit")
+        return "\n".join(lines)
+
     def owned_ranges(self):
-        """Element ranges this rank updates: everything (allreduce) or its shard of every bucket (ps)."""
-        if self.mode == "allreduce" or not self.dist:
-            return None
-        return [self.arena.shard_range(b, self.rank, self.world) for b in range(len(self.arena.buckets))]
+        """Element ranges this rank updates: everything in this mode (``None``); the PS subclass returns its shards."""
+        return None
 
     def gather_parameters(self) -> None:
-        """PS mode: all-gather the updated master shards (pull), then refresh the bf16 shadow."""
-        if self.mode != "ps" or not self.dist:
-            return
-        a = self.arena
-        handles = []
-        for b in range(len(a.buckets)):
-            full = a.bucket_master(b)
-            lo, hi = a.shard_range(b, self.rank, self.world)
-            own = a.master[lo:hi]
-            if self.ncomm is not None:
-                handles.append(self.ncomm.all_gather(full, own))
-            elif self.backend == "nccl":
-                handles.append(td.all_gather_into_tensor(full, own, group=self.pg, async_op=True))
-            else:
-                n = hi - lo
-                views = [full[r * n:(r + 1) * n] for r in range(self.world)]
-                handles.append(td.all_gather(views, own.clone(), group=self.pg, async_op=True))
-        for h in handles:
-            h.wait()
-        a.sync_shadow()
+        """No-op here; the PS subclass pulls the updated shards."""
+
+    def prepare_checkpoint(self) -> None:
+        """Make ``state_dict()`` of the wrapped module exact on this rank (no-op: every rank holds full fp32 masters)."""
 
     def attach(self, optimizer) -> None:
-        """Wire an arena optimizer for the PS mode (sharded LARS norms need a cross-rank sum)."""
-        if self.mode == "ps" and self.dist and hasattr(optimizer, "norm_reduce"):
-            optimizer.norm_reduce = lambda norms: td.all_reduce(norms, op=td.ReduceOp.SUM, group=self.pg)
+        """Wire an arena optimizer to this reducer (the PS subclass shards its state and norms)."""
 
     def step(self, optimizer) -> None:
-        """finish grad sync -> (sharded) optimizer step -> (PS) parameter all-gather."""
+        """finish grad sync -> optimizer step."""
         self.finish_grad_sync()
         if self.on_synced is not None:
             self.on_synced()
-        optimizer.step(ranges=self.owned_ranges())
-        if self.mode == "ps" and self.dist:
-            # non-owned gradient ranges were not cleared by the sharded step
-            self.arena.zero_grad()
-            self.gather_parameters()
+        optimizer.step()
 
     class _NoSync:
         def __init__(self, ddp):
@@ -270,6 +475,14 @@ class DistributedDataParallel(tnn.Module):
         """Gradient accumulation: skip communication inside the context."""
         return DistributedDataParallel._NoSync(self)
 
+    def close(self) -> None:
+        """Stop the watchdog and release the native communicator (idempotent)."""
+        if self.watchdog is not None:
+            self.watchdog.stop()
+        if self.ncomm is not None:
+            self.ncomm.close()
+            self.ncomm = None
+
     # state_dict passthrough: checkpoints carry the wrapped module's keys (torchvision-compatible)
     def state_dict(self, *args, **kwargs):
         return self.module.state_dict(*args, **kwargs)
@@ -279,13 +492,18 @@ class DistributedDataParallel(tnn.Module):
         self.arena.sync_shadow()
         return out
 
+    def _checksum_source(self) -> torch.Tensor:
+        return self.arena.master
+
     def param_checksum(self) -> torch.Tensor:
-        """Debug aid: max |w_rank - w_rank0| surrogate — (sum, sum of squares) of the master arena, all-gathered.
+        """Debug aid: max |w_rank - w_rank0| surrogate — (sum, sum of squares) of the parameters, all-gathered.
         Catches silent replica divergence (the reference's spawn-mode no-sync bug)."""
-        a = self.arena.master.double()
-        local = torch.stack([a.sum(), (a * a).sum()]).to(self.arena.device)
+        a = self._checksum_source().double()
+        local = torch.stack([a.sum(), (a * a).sum()])
         if not self.dist:
             return local.unsqueeze(0)
+        if self.staged:
+            local = local.cpu()
         out = [torch.zeros_like(local) for _ in range(self.world)]
         td.all_gather(out, local, group=self.pg)
-        return torch.stack(out)
+        return torch.stack(out).to(self.arena.device)

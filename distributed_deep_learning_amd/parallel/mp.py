@@ -17,6 +17,8 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 import torch.nn as tnn
 
+from ..ops._lib import device_of
+
 
 # ----------------------------------------------------------------------------------------------- partitioning
 def partition_layers(n_layers: int, n_stages: int, weights: Optional[Sequence[float]] = None) -> List[int]:
@@ -153,10 +155,14 @@ class StagedModel(tnn.Module):
         self.stages = tnn.ModuleList(tnn.Sequential(*g) for g in groups)
 
     def run_stage(self, i: int, x):
+        """Stage ``i`` on ``devices[i]``: the peer copy and every kernel of the stage are issued with that GPU as the
+        current device, so the hand-written kernels (which launch on the current device's stream) run where their
+        operands live, ordered with the ATen work and the copy on that device's stream."""
         dev = self.devices[i]
-        if isinstance(x, torch.Tensor) and x.device != dev:
-            x = x.to(dev, non_blocking=True)
-        return self.stages[i](x)
+        with device_of(dev):
+            if isinstance(x, torch.Tensor) and x.device != dev:
+                x = x.to(dev, non_blocking=True)
+            return self.stages[i](x)
 
     def forward(self, x):
         for i in range(len(self.stages)):

@@ -7,8 +7,15 @@ the compute streams is explicit (events), and calls that are plain stream operat
 (any backend) or a ``TCPStore``.  RCCL itself is the copy torch ships (``torch/lib/librccl.so``), resolved with
 ``dlopen`` so the process never maps two RCCLs.
 
-Opt-in (``DistributedDataParallel(comm="native")`` / ``--comm native``): this box can only exercise it with one
-rank (identity collectives), the multi-rank path of record is ``torch.distributed``.
+Default transport of the GPU reducer (``DistributedDataParallel(comm="native")`` / ``--comm native``); the reducer
+compares one all-reduce with ``torch.distributed``'s at start-up and every rank falls back together if they differ.
+The stream has normal priority on purpose: a high-priority stream that waits on events of normal-priority streams is
+the pattern behind the GPU-side deadlocks recorded in ``docs/STATUS.md``.
+
+Tuning for the xGMI mesh (7 point-to-point links per GPU) is RCCL's environment, passed through untouched:
+``NCCL_MIN_NCHANNELS`` / ``NCCL_MAX_NCHANNELS`` (channels, i.e. links driven at once), ``NCCL_ALGO`` (``Ring`` is
+per-link bound: 2(N-1)/N x S / 153 GB/s; ``Tree`` / direct algorithms use more links for small N),
+``NCCL_PROTO``, ``NCCL_BUFFSIZE``; the bucket size is ``--bucket-mb``.
 
 Reference behaviour replaced: blocking per-parameter ``all_reduce`` through c10d
 (``/root/reference/src/pytorch/CNN/main.py:134-140``).
@@ -79,6 +86,13 @@ class NativeCommunicator:
     def version(self) -> int:
         return self.lib.ddl_comm_version()
 
+    def ranks(self) -> int:
+        """Number of ranks the RCCL communicator itself reports (``ncclCommCount``)."""
+        return int(self.lib.ddl_comm_count(self._comm))
+
+    def user_rank(self) -> int:
+        return int(self.lib.ddl_comm_user_rank(self._comm))
+
     # ------------------------------------------------------------------ plumbing
     def _enter(self) -> int:
         """Order the comm stream behind everything enqueued on the current stream; returns its raw handle."""
@@ -123,6 +137,20 @@ class NativeCommunicator:
         st = self._enter()
         check(self.lib.ddl_comm_broadcast(self._comm, t.data_ptr(), t.numel(), self._dt(t), root, st), "ncclBroadcast")
         return self._done()
+
+    def barrier(self) -> None:
+        """All ranks have enqueued everything before this call AND it has finished on every GPU: a one-element
+        all-reduce on the communicator's stream, then a host wait for it."""
+        if getattr(self, "_bar", None) is None:
+            self._bar = torch.zeros(8, dtype=torch.float32, device=self.device)
+        self.all_reduce(self._bar, average=False)
+        self.stream.synchronize()
+
+    def abort(self) -> None:
+        """Give up on outstanding collectives (``ncclCommAbort``): a rank leaving a hung job."""
+        if getattr(self, "_comm", None):
+            self.lib.ddl_comm_abort(self._comm)
+            self._comm = None
 
     def close(self) -> None:
         if getattr(self, "_comm", None):

@@ -1,31 +1,241 @@
 """Parameter-server-style synchronisation (the idiom of the reference's empty MXNet / TensorFlow / Paddle stubs,
-``/root/reference/src/{mxnet,tensorflow,paddle}/**``, SURVEY §2.3 "PS-style sync").
+``/root/reference/src/{mxnet,tensorflow,paddle}/**``, SURVEY §2.3 "PS-style sync") — a ZeRO-1 sharded data-parallel
+step.  There is no server process: every rank IS the server of its shard.  Per bucket of the flat arena
 
-There is no server process: every rank IS the server of its shard.  Per bucket of the flat arena
-
-    push   reduce_scatter(grad bucket)            -> each rank holds the averaged gradient of ITS shard
-    update fused SGD / LARS / Adam on the shard    (fp32 master + momentum only for 1/world of the parameters;
-                                                    LARS norms of tensors cut by shard borders are all-reduced)
-    pull   all_gather(master shards)               -> every rank has the full updated parameters again
+    push    reduce_scatter(grad bucket)          each rank holds the averaged gradient of ITS shard only
+    update  fused SGD / LARS / Adam on the shard  fp32 master + optimizer state exist for 1/world of the parameters
+                                                  (``optimizer.shard_state``); LARS norms of tensors cut by shard
+                                                  borders are summed over ranks
+    pull    all_gather(updated shards)            GPU: the bf16 SHADOW travels (half the bytes of the fp32 master);
+                                                  the few 1-D parameters that kernels read in fp32 (BN affine, biases)
+                                                  follow in one small fp32 all-reduce; CPU (no shadow): fp32 master
 
 which on the fully connected xGMI mesh moves S/N bytes to each of the 7 peers at once instead of walking a ring.
-The machinery lives in :class:`.ddp.DistributedDataParallel` (``mode="ps"``); this module is the named entry point.
+
+What each rank holds after a step on the GPU: exact fp32 masters for its own shards and for every 1-D tensor, the
+bf16-rounded value (``float(shadow)``) for the rest — every replica computes with identical numbers (filters are
+consumed in bf16 anyway).  ``prepare_checkpoint()`` all-gathers the fp32 master shards and the optimizer-state shards
+when a checkpoint is written, so checkpoints are exact, complete and independent of the world size that wrote them.
 """
 from __future__ import annotations
 
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as td
+
+from ..ops._lib import device_of
 from .ddp import DistributedDataParallel
 
 
 class ShardedDataParallel(DistributedDataParallel):
-    """``DistributedDataParallel`` fixed to the reduce-scatter -> sharded step -> all-gather schedule (ZeRO-1-like)."""
+    """``DistributedDataParallel`` on the reduce-scatter -> sharded step -> all-gather schedule (ZeRO-1)."""
 
-    def __init__(self, module, **kw):
-        kw.pop("mode", None)
-        super().__init__(module, mode="ps", **kw)
+    def __init__(self, module, *args, **kw):
+        if len(args) > 1:                                   # (bucket_mb, mode, ...) given positionally
+            args = (args[0], "ps") + tuple(args[2:])
+        else:
+            kw["mode"] = "ps"
+        super().__init__(module, *args, **kw)
+        self._small_idx: Optional[torch.Tensor] = None
+        self._optimizer = None
+        self.bf16_pull = self.dist and self.arena.shadow is not None and self.on_gpu
+        if self.bf16_pull:
+            self._build_small_table()
+
+    # ------------------------------------------------------------------ layout
+    def owned_ranges(self) -> Optional[List[Tuple[int, int]]]:
+        if not self.dist:
+            return None
+        return [self.arena.shard_range(b, self.rank, self.world) for b in range(len(self.arena.buckets))]
+
+    def _build_small_table(self) -> None:
+        """Index tables of the 1-D tensors (consumed in fp32 by the kernels): positions in the arena, and a 0/1 mask of
+        the positions this rank owns.  ~53k elements for ResNet-50."""
+        a = self.arena
+        idx, own = [], []
+        ranges = self.owned_ranges() or []
+        for p, s in zip(a.params, a.segments):
+            if p.dim() > 1:
+                continue
+            lo, hi = ranges[s.bucket]
+            r = torch.arange(s.offset, s.offset + s.numel, dtype=torch.int64)
+            idx.append(r)
+            own.append((r >= lo) & (r < hi))
+        if idx:
+            self._small_idx = torch.cat(idx).to(a.device)
+            self._small_own = torch.cat(own).to(a.device)
+
+    # ------------------------------------------------------------------ push
+    def _launch_collective(self, b: int, g: torch.Tensor) -> None:
+        inv = 1.0 / self.world
+        src = g if self.grad_dtype is None else self._pack(b, g)
+        lo, hi = self.arena.shard_range(b, self.rank, self.world)
+        dst = self.arena.grad[lo:hi]
+        off = lo - self.arena.buckets[b].lo
+        scale = False
+        if self.ncomm is not None:
+            part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
+            h = self.ncomm.reduce_scatter(part, src, average=True)
+        elif self.backend == "nccl":
+            part = dst if src is g else self._comm_buf(("shard", b), hi - lo)
+            h = td.reduce_scatter_tensor(part, src, op=td.ReduceOp.AVG, group=self.pg, async_op=True)
+        else:   # gloo has no reduce-scatter: same semantics via all-reduce, only the owned shard is used
+            h = self._all_reduce_sum_async(src, ("bucket", b))
+            part, scale = src[off:off + (hi - lo)], True
+
+        def finish(dst=dst, part=part, scale=scale):
+            if part.data_ptr() != dst.data_ptr() or part.dtype != dst.dtype:
+                self._unpack(dst, part)
+            if scale:
+                dst.mul_(inv)
+
+        self._handles.append((b, h, finish))
+
+    # ------------------------------------------------------------------ pull
+    def _all_gather(self, full: torch.Tensor, own: torch.Tensor):
+        """``full`` = world x ``own`` in rank order (``own`` may alias its slot of ``full``).  Returns a waitable."""
+        if self.ncomm is not None and own.dtype in (torch.float32, torch.bfloat16):
+            return self.ncomm.all_gather(full, own)
+        if self.backend == "nccl":
+            return td.all_gather_into_tensor(full, own, group=self.pg, async_op=True)
+        n = own.numel()
+        if self.staged and own.is_cuda:
+            host_full = torch.empty(full.numel(), dtype=full.dtype)
+            views = [host_full[r * n:(r + 1) * n] for r in range(self.world)]
+            td.all_gather(views, own.detach().cpu(), group=self.pg)
+            full.copy_(host_full)
+            return None
+        views = [full[r * n:(r + 1) * n] for r in range(self.world)]
+        return td.all_gather(views, own.clone(), group=self.pg, async_op=True)
+
+    def gather_parameters(self) -> None:
+        """Pull: every rank gets the updated parameters of all shards (see the module docstring for what travels)."""
+        if not self.dist:
+            return
+        a = self.arena
+        handles = []
+        for b in range(len(a.buckets)):
+            bk = a.buckets[b]
+            lo, hi = a.shard_range(b, self.rank, self.world)
+            if self.bf16_pull:
+                handles.append(self._all_gather(a.shadow[bk.lo:bk.hi], a.shadow[lo:hi]))
+            else:
+                handles.append(self._all_gather(a.master[bk.lo:bk.hi], a.master[lo:hi]))
+        for h in handles:
+            if h is not None:
+                h.wait()
+        if self.bf16_pull:
+            self._refresh_foreign_masters()
+            a.refresh_transposes()
+            a.mark_shadow_current()
+        else:
+            a.sync_shadow()
+
+    def _refresh_foreign_masters(self) -> None:
+        """fp32 masters of the ranges other ranks own: 1-D tensors exactly (one small fp32 all-reduce of the owned
+        values, zero elsewhere), everything else from the gathered bf16 shadow."""
+        a = self.arena
+        from ..ops import kernels as K
+        for b in range(len(a.buckets)):
+            bk = a.buckets[b]
+            lo, hi = a.shard_range(b, self.rank, self.world)
+            if lo > bk.lo:
+                K.cast_bf16_f32(a.shadow[bk.lo:lo], a.master[bk.lo:lo])
+            if hi < bk.hi:
+                K.cast_bf16_f32(a.shadow[hi:bk.hi], a.master[hi:bk.hi])
+        if self._small_idx is not None:
+            vals = a.master.index_select(0, self._small_idx)
+            small = torch.where(self._small_own, vals, torch.zeros_like(vals))
+            if self.ncomm is not None:
+                self.ncomm.all_reduce(small, average=False).wait()
+            else:
+                td.all_reduce(small, op=td.ReduceOp.SUM, group=self.pg)
+            a.master.index_copy_(0, self._small_idx, small)
+
+    def gather_master(self) -> None:
+        """Exact fp32 masters of every shard on every rank (checkpoint time)."""
+        if not self.dist:
+            return
+        a = self.arena
+        handles = []
+        for b in range(len(a.buckets)):
+            bk = a.buckets[b]
+            lo, hi = a.shard_range(b, self.rank, self.world)
+            handles.append(self._all_gather(a.master[bk.lo:bk.hi], a.master[lo:hi]))
+        for h in handles:
+            if h is not None:
+                h.wait()
+
+    def gather_flat(self, compact: torch.Tensor) -> torch.Tensor:
+        """A per-shard ("compact", owned ranges back to back in bucket order) fp32 buffer of every rank -> the full
+        arena-layout buffer.  Collective; used for optimizer state when a checkpoint is written."""
+        a = self.arena
+        full = torch.zeros(a.total, dtype=compact.dtype, device=compact.device)
+        if not self.dist:
+            full.copy_(compact)
+            return full
+        off = 0
+        handles = []
+        for b in range(len(a.buckets)):
+            bk = a.buckets[b]
+            n = (bk.hi - bk.lo) // self.world
+            handles.append(self._all_gather(full[bk.lo:bk.hi], compact[off:off + n]))
+            off += n
+        for h in handles:
+            if h is not None:
+                h.wait()
+        return full
+
+    def prepare_checkpoint(self) -> None:
+        if self.dist and self.bf16_pull:
+            self.gather_master()
+
+    def _checksum_source(self) -> torch.Tensor:
+        # foreign fp32 masters are bf16-rounded copies under the bf16 pull: compare what the replicas compute with
+        return self.arena.shadow if self.bf16_pull else self.arena.master
+
+    # ------------------------------------------------------------------ optimizer wiring
+    def attach(self, optimizer) -> None:
+        """Shard the optimizer: state only for the owned ranges, LARS norms summed over ranks, state gathered for
+        checkpoints through this reducer."""
+        self._optimizer = optimizer
+        if not self.dist:
+            return
+        if hasattr(optimizer, "shard_state"):
+            optimizer.shard_state(self.owned_ranges(), gather=self.gather_flat)
+        if hasattr(optimizer, "norm_reduce"):
+            if self.ncomm is not None:
+                optimizer.norm_reduce = lambda norms: self.ncomm.all_reduce(norms, average=False).wait()
+            elif self.staged:
+                def reduce(norms):
+                    host = norms.cpu()
+                    td.all_reduce(host, op=td.ReduceOp.SUM, group=self.pg)
+                    norms.copy_(host)
+                optimizer.norm_reduce = reduce
+            else:
+                optimizer.norm_reduce = lambda norms: td.all_reduce(norms, op=td.ReduceOp.SUM, group=self.pg)
+
+    def step(self, optimizer) -> None:
+        """push (finish the reduce-scatters) -> sharded update -> pull."""
+        self.finish_grad_sync()
+        if self.on_synced is not None:
+            self.on_synced()
+        optimizer.step(ranges=self.owned_ranges())
+        if self.dist:
+            with device_of(self.arena.device):
+                self.arena.zero_grad()      # non-owned gradient ranges were not cleared by the sharded step
+                self.gather_parameters()
+
+    def state_bytes_per_rank(self) -> Dict[str, int]:
+        """Bytes of optimizer state this rank holds, per state tensor (= total / world once attached)."""
+        opt = self._optimizer
+        return {} if opt is None else {k: v.numel() * v.element_size() for k, v in opt.flat_state.items()}
 
 
 def wrap(module, sync: str = "allreduce", **kw) -> DistributedDataParallel:
     """``sync`` = ``"allreduce"`` | ``"ps"`` (the ``--sync`` flag)."""
+    kw.pop("mode", None)
     if sync == "ps":
         return ShardedDataParallel(module, **kw)
     return DistributedDataParallel(module, mode="allreduce", **kw)

@@ -135,7 +135,11 @@ class Trainer:
                 self.ddps.append(None)
                 continue
             if info.world > 1:
-                d = DistributedDataParallel(g, bucket_mb=cfg.bucket_mb, mode=cfg.sync,
+                # the arena is built here, with the same stage-qualified names as the single-rank path, so optimizer
+                # state in a checkpoint maps onto any world size / sync mode by name
+                arena = ParamArena(named, bucket_bytes=int(cfg.bucket_mb * 2**20),
+                                   shard_multiple=info.world if cfg.sync == "ps" else 1)
+                d = DistributedDataParallel(g, bucket_mb=cfg.bucket_mb, mode=cfg.sync, arena=arena,
                                             grad_dtype=torch.bfloat16 if cfg.grad_dtype == "bf16" else None,
                                             comm=cfg.comm if self.in_device.type == "cuda" else "torch")
                 if isinstance(model, StagedModel):
@@ -177,20 +181,22 @@ class Trainer:
         cfg, info = self.cfg, self.info
         if cfg.data:
             from .data.files import open_dataset
-            ds = open_dataset(cfg.model, cfg.data, seed=cfg.seed)
+            ds = open_dataset(cfg.model, cfg.data, seed=cfg.seed, lazy=cfg.nworkers > 0)
         elif wl is not None:
             ds = wl[0](cfg.samples, cfg.seed)
         elif cfg.model.startswith("vgg") or cfg.model in ("resnet18", "resnet34", "resnet50", "resnet101"):
             ds = syn.imagenet_like(cfg.samples, cfg.seed, classes=cfg.classes or 1000)
         else:
             raise KeyError(f"no default dataset for model {cfg.model}")
-        if hasattr(ds, "to") and self.in_device.type == "cuda":
+        if hasattr(ds, "to") and self.in_device.type == "cuda" and not (cfg.data and cfg.nworkers > 0):
             ds = ds.to(self.in_device)                       # synthetic data lives on the device: zero H2D per step
         self.dataset = ds
         tr, va, te = split_indices(len(ds), cfg.split, seed=cfg.seed)
-        mk = lambda idx, shuffle: BatchLoader(  # noqa: E731
-            ds, ShardedSampler(idx, info.rank, info.world, shuffle=shuffle, seed=cfg.seed), cfg.batch,
-            device=self.in_device, prefetch=False)
+        # training shards are padded to equal length (collectives must pair up); evaluation shards are NOT, so
+        # metrics reduced over ranks count every sample exactly once
+        mk = lambda idx, train: BatchLoader(  # noqa: E731
+            ds, ShardedSampler(idx, info.rank, info.world, shuffle=train, seed=cfg.seed, pad=train), cfg.batch,
+            device=self.in_device, prefetch=cfg.nworkers > 0, workers=cfg.nworkers)
         self.train_loader, self.val_loader, self.test_loader = mk(tr, True), mk(va, False), mk(te, False)
 
     # ------------------------------------------------------------------ one step
@@ -342,6 +348,10 @@ class Trainer:
         return self.model
 
     def save(self, path: str) -> None:
+        """Collective: every rank calls it (PS mode gathers master and optimizer-state shards), rank 0 writes."""
+        for d in self.ddps:
+            if d is not None:
+                d.prepare_checkpoint()
         opt_state = [o.state_dict() for o in self.optimizers]
         sch_state = [s.state_dict() for s in self.schedulers]
         ckpt.save(path, self._ckpt_model(), epoch=self.epoch, step=self.global_step,

@@ -45,9 +45,10 @@ class GraphedTrainStep:
         if ddp is not None and ddp.dist and ddp.ncomm is None:
             raise NotImplementedError("graph capture of torch.distributed collectives is not supported: build the "
                                       "reducer with comm='native' or run the step eagerly")
-        if (ddp is not None and ddp.dist and ddp.mode == "ps" and getattr(optimizer, "norm_reduce", None) is not None
-                and optimizer.param_groups[0].get("lars")):
-            raise NotImplementedError("sharded LARS all-reduces its norms through torch.distributed: not capturable")
+        if (ddp is not None and ddp.dist and ddp.mode == "ps" and ddp.ncomm is None
+                and getattr(optimizer, "norm_reduce", None) is not None and optimizer.param_groups[0].get("lars")):
+            raise NotImplementedError("sharded LARS all-reduces its norms through torch.distributed: not capturable "
+                                      "(the native communicator's norm all-reduce is)")
         self.ddp = ddp if (ddp is not None and ddp.dist) else None
         self.fwd = ddp if ddp is not None else model
         for m in model.modules():
@@ -73,6 +74,11 @@ class GraphedTrainStep:
         torch.cuda.current_stream(example_x.device).wait_stream(s)
         torch.cuda.synchronize(example_x.device)
 
+        # Derived weight copies that are NOT arena-backed (bf16 packs of the stem / pad_out filters, LSTM packs, Linear
+        # weights) are cached per weights epoch.  The warm-up refreshed them; a capture would bake in addresses of
+        # copies that training makes stale, so force them to be re-derived INSIDE the graph ...
+        from ..ops import state as _state
+        _state.bump()
         self.optimizer.host_prepare()
         with torch.cuda.graph(self.graph):
             self.loss = self._forward_backward()
@@ -86,6 +92,10 @@ class GraphedTrainStep:
             else:
                 streams.join()
                 self.optimizer.launch()
+        # ... and the copies cached DURING the capture live in the graph's private pool and were never executed (a
+        # capture records launches without running them): an eager step or evaluation right after the capture - a
+        # ragged last batch, --max-steps 1 - must not read them.  Invalidate them for every eager caller.
+        _state.bump()
         self.correct = getattr(self.criterion, "last_correct", None)
         # Capturing records the launches without running them: undo the host-side bookkeeping of that "step".
         self.optimizer.step_count -= 1
