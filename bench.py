@@ -194,11 +194,19 @@ def run_rank(a) -> int:
     for _ in range(a.warmup):
         loss = step()
     fence()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step GPU time (diagnostics only)
+    ms0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    marks[0].record()
+    for i in range(a.steps):
         loss = step()
+        marks[i + 1].record()
     fence()
     dt_local = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(a.steps))
+    ms1 = torch.cuda.memory_stats(dev)
+    alloc_diag = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
+    alloc_diag["reserved_gib"] = round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 2)
     tmax = torch.tensor([dt_local], dtype=torch.float64, device=dev)
     tmin = tmax.clone()
     if info.world > 1:
@@ -223,6 +231,8 @@ def run_rank(a) -> int:
             "rccl_ranks": (ddp.comm_ranks() if ddp is not None and ddp.dist else 1),
             "ms_per_step_rank_min": round(1e3 * float(tmin.item()) / a.steps, 3),
             "ms_per_step_rank_max": round(1e3 * dt / a.steps, 3),
+            "gpu_step_ms_min_median_max": [round(step_ms[0], 3), round(step_ms[len(step_ms) // 2], 3), round(step_ms[-1], 3)],
+            "allocator_in_timed_region": alloc_diag,
             "bucket_plan_mib": [round((b.hi - b.lo) * 4 / 2**20, 2) for b in arena.buckets],
             "launcher": "self" if os.environ.get("DDL_BENCH_SELF_LAUNCHED") else info.launcher,
             "comm_note": comm_note,

@@ -1,7 +1,9 @@
 // Fused BatchNorm(+residual add)(+ReLU) for NHWC bf16 activations on gfx950.  All kernels are HBM-bound:
 // 16-byte (8 x bf16) accesses per lane, every thread keeps its channel chunk fixed so the per-channel
-// coefficients live in registers, and reductions go wave -> LDS -> a small [nslots][2][C] fp32 slab with float
-// atomics (the slab spreads same-address contention; a finalize kernel folds it).
+// coefficients live in registers, and reductions go wave -> LDS -> a small [nslots][2][C] fp64 slab with atomics
+// (the slab spreads same-address contention; a finalize kernel folds it).  Forward statistics are accumulated in
+// fp32 about a per-block pivot and converted to plain fp64 sums before they leave the block (common.h), so the
+// variance survives |mean| >> std.
 //
 // forward  (train): stats (or the conv epilogue's fused partials) -> finalize (mean, invstd, scale, shift,
 //                   running stats) -> apply  y = act(x*scale + shift [+ res])
@@ -55,37 +57,53 @@ static inline dim3 rowmap_grid(const RowMap& r, int max_x = 2048) {
 // ---------------------------------------------------------------- forward: statistics
 __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict__ x, float* __restrict__ slab,
                                                        RowMap rm) {
-  __shared__ float red[256 * 16];
+  __shared__ float red[256 * 17];       // per thread: 8 shifted sums, 8 shifted sums of squares, row count
+  __shared__ float piv[256 * 8];        // per chunk column: the block's pivot (its first row)
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
   const int chunk = blockIdx.y * rm.cpb + col;
   const bool active = (rg < rm.rp) && (chunk < rm.c8);
-  float s1[8], s2[8];
+  float s1[8], s2[8], k[8];
+  float cnt = 0.f;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; k[q] = 0.f; }
   if (active) {
+    // pivot: the first row this block visits (the same for every row group of a column)
+    const int prow = min((int)(blockIdx.x * rm.rp), rm.M - 1);
+    unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)prow * rm.C + (size_t)chunk * 8), k);
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
       const u32x4 v = ld_stream(x + (size_t)row * rm.C + (size_t)chunk * 8);
       float f[8];
       unpack8(v, f);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+      for (int q = 0; q < 8; ++q) { const float d = f[q] - k[q]; s1[q] += d; s2[q] += d * d; }
+      cnt += 1.f;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { red[tid * 16 + q] = s1[q]; red[tid * 16 + 8 + q] = s2[q]; }
+  for (int q = 0; q < 8; ++q) { red[tid * 17 + q] = s1[q]; red[tid * 17 + 8 + q] = s2[q]; }
+  red[tid * 17 + 16] = cnt;
+  if (rg == 0) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) piv[col * 8 + q] = k[q];
+  }
   __syncthreads();
-  // thread (col, q, which) sums over row groups
-  const int nout = rm.cpb * 16;
+  // thread (col, q) folds the row groups and hands plain fp64 sums to the slab
+  const int nout = rm.cpb * 8;
   for (int o = tid; o < nout; o += 256) {
-    const int c = o / 16, e = o % 16;          // e: 0..7 sum, 8..15 sumsq
+    const int c = o / 8, q = o % 8;
     const int ch = blockIdx.y * rm.cpb + c;
     if (ch >= rm.c8) continue;
-    float s = 0.f;
-    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
-    const int which = e >> 3, q = e & 7;
+    float a = 0.f, b = 0.f, n = 0.f;
+    for (int g = 0; g < rm.rp; ++g) {
+      const float* r = red + (g * rm.cpb + c) * 17;
+      a += r[q]; b += r[8 + q]; n += r[16];
+    }
+    double sx, sxx;
+    unshift_sums(a, b, piv[c * 8 + q], (double)n, sx, sxx);
     const int slot = blockIdx.x % BN_SLOTS;
-    atomicAdd(&slab[((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q], s);
+    slab_add(slab, ((size_t)slot * 2 + 0) * rm.C + (size_t)ch * 8 + q, sx);
+    slab_add(slab, ((size_t)slot * 2 + 1) * rm.C + (size_t)ch * 8 + q, sxx);
   }
 }
 
@@ -93,18 +111,19 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
 // the four partials meet in LDS.  Returns the two sums for channel c (valid in threads with threadIdx.x < 64).
 // The slab is SELF-CLEANING: every entry is zeroed right after it is read, so a slab that starts at zero (one
 // memset at allocation) can be reused by the next accumulate -> finalize pair without a memset launch.
-__device__ __forceinline__ void slab_fold(float* __restrict__ slab, int nslots, int C, float& s1, float& s2) {
-  __shared__ float part[4][2][64];
+__device__ __forceinline__ void slab_fold(float* __restrict__ slab_f, int nslots, int C, double& s1, double& s2) {
+  __shared__ double part[4][2][64];
+  double* __restrict__ slab = reinterpret_cast<double*>(slab_f);
   const int cc = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cc;
-  float a = 0.f, b = 0.f;
+  double a = 0.0, b = 0.0;
   if (c < C) {
 #pragma unroll 4
     for (int s = w; s < nslots; s += 4) {
-      float* p0 = slab + ((size_t)s * 2 + 0) * C + c;
-      float* p1 = slab + ((size_t)s * 2 + 1) * C + c;
+      double* p0 = slab + ((size_t)s * 2 + 0) * C + c;
+      double* p1 = slab + ((size_t)s * 2 + 1) * C + c;
       a += *p0; b += *p1;
-      *p0 = 0.f; *p1 = 0.f;
+      *p0 = 0.0; *p1 = 0.0;
     }
   }
   part[w][0][cc] = a;
@@ -120,12 +139,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(float* __restrict__ sl
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
                                    float* __restrict__ scale, float* __restrict__ shift) {
-  float s1, s2;
+  double s1, s2;
   slab_fold(slab, nslots, C, s1, s2);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || c >= C) return;
-  const float mu = s1 / count;
-  float var = s2 / count - mu * mu;
+  const double mud = s1 / (double)count;
+  const float mu = (float)mud;
+  float var = (float)(s2 / (double)count - mud * mud);      // the subtraction that must not happen in fp32
   var = fmaxf(var, 0.f);
   const float is = rsqrtf(var + eps);
   mean[c] = mu;
@@ -331,7 +351,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
     const int which = e >> 3, q = e & 7;
     const int slot = blockIdx.x % BN_SLOTS;
-    atomicAdd(&slab[((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q], s);
+    slab_add(slab, ((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q, (double)s);
   }
 }
 
@@ -341,12 +361,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
                                        const float* __restrict__ invstd, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int accumulate, float* __restrict__ coefA,
                                        float* __restrict__ coefB, float* __restrict__ coefC, int raw = 0) {
-  float sg, sgx;
-  slab_fold(slab, nslots, C, sg, sgx);
+  double sgd, sgxd;
+  slab_fold(slab, nslots, C, sgd, sgxd);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || c >= C) return;
+  float sg = (float)sgd, sgx = (float)sgxd;
   // raw: the slab holds sum(g), sum(g*x) from a dgrad epilogue (conv_epilogue.h) instead of sum(g*xhat)
-  if (raw) sgx = invstd[c] * (sgx - mean[c] * sg);
+  if (raw) sgx = invstd[c] * (float)(sgxd - (double)mean[c] * sgd);
   if (accumulate) { dgamma[c] += sgx; dbeta[c] += sg; }      // straight into the arena gradient
   else            { dgamma[c] = sgx;  dbeta[c] = sg; }
   const float g = gamma ? gamma[c] : 1.f;
@@ -454,12 +475,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce2_kernel(const bf16_t* __res
     const int slot = blockIdx.x % BN_SLOTS;
     const size_t cidx = (size_t)ch * 8 + q;
     if (which == 0) {                                   // sum(g) belongs to both
-      atomicAdd(&slab_a[((size_t)slot * 2) * rm.C + cidx], s);
-      atomicAdd(&slab_b[((size_t)slot * 2) * rm.C + cidx], s);
+      slab_add(slab_a, ((size_t)slot * 2) * rm.C + cidx, (double)s);
+      slab_add(slab_b, ((size_t)slot * 2) * rm.C + cidx, (double)s);
     } else if (which == 1) {
-      atomicAdd(&slab_a[((size_t)slot * 2 + 1) * rm.C + cidx], s);
+      slab_add(slab_a, ((size_t)slot * 2 + 1) * rm.C + cidx, (double)s);
     } else {
-      atomicAdd(&slab_b[((size_t)slot * 2 + 1) * rm.C + cidx], s);
+      slab_add(slab_b, ((size_t)slot * 2 + 1) * rm.C + cidx, (double)s);
     }
   }
 }
@@ -508,11 +529,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply2_kernel(const bf16_t* __rest
 // Row 0 of a reduction slab -> out[c] (+)= sum over slots; the slab is left zero (both rows).
 __global__ __launch_bounds__(256) void slab_fold_kernel(float* __restrict__ slab, int nslots, int C, float* __restrict__ out,
                                                         int accumulate) {
-  float s1, s2;
+  double s1, s2;
   slab_fold(slab, nslots, C, s1, s2);
   const int c = blockIdx.x * 64 + threadIdx.x;
   if (threadIdx.x >= 64 || c >= C) return;
-  if (accumulate) out[c] += s1; else out[c] = s1;
+  if (accumulate) out[c] += (float)s1; else out[c] = (float)s1;
 }
 
 // ================================================================ C ABI
@@ -525,7 +546,7 @@ extern "C" int ddl_slab_fold(float* slab, int C, float* out, int accumulate, voi
 
 extern "C" int ddl_bn_slots() { return BN_SLOTS; }
 
-// slab: [BN_SLOTS][2][C] fp32 workspace, must be ZERO on entry (finalize re-zeroes it: self-cleaning).
+// slab: [BN_SLOTS][2][C] fp64 workspace (passed as float*), must be ZERO on entry (finalize re-zeroes it: self-cleaning).
 extern "C" int ddl_bn_stats(const void* x, float* slab, int M, int C, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;

@@ -14,8 +14,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 typedef unsigned short bf16_t;                                 // raw bf16 bits in global memory
 
 #define DDL_WAVE 64
-// Reduction slabs ([DDL_BN_SLOTS][2][C] fp32) spread same-address float atomics over this many copies.
+// Reduction slabs ([DDL_BN_SLOTS][2][C] fp64) spread same-address atomics over this many copies.  The sums are kept
+// in DOUBLE: BatchNorm's variance is E[x^2] - E[x]^2, which cancels catastrophically in fp32 once |mean| >> std;
+// producers accumulate fp32 partials about a per-tile pivot, convert them to plain sums in fp64 (exact to ~1e-16) and
+// add those (global_atomic_add_f64), the finalize kernels subtract in fp64.  The C ABI still passes `float*`.
 #define DDL_BN_SLOTS 64
+typedef double slab_t;
+__device__ __forceinline__ void slab_add(float* slab, size_t idx, double v) {
+  atomicAdd(reinterpret_cast<double*>(slab) + idx, v);
+}
+// fp32 sums about a pivot k over n elements -> plain sums:  sum x = s1 + n k ;  sum x^2 = s2 + 2 k s1 + n k^2
+__device__ __forceinline__ void unshift_sums(float s1, float s2, float k, double n, double& sx, double& sxx) {
+  const double kd = (double)k, a = (double)s1;
+  sx = a + n * kd;
+  sxx = (double)s2 + 2.0 * kd * a + n * kd * kd;
+}
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __uint_as_float(((unsigned int)v) << 16);

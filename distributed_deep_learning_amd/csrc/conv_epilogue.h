@@ -49,9 +49,12 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
   constexpr int RPP = 512 / CPR;    // rows per pass
   const int oc = tid % CPR, orow0 = tid / CPR;
   const int ncol = n0 + oc * 8;
-  float s1[8], s2[8];
+  float s1[8], s2[8], kf[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; kf[q] = 0.f; }
+  // forward statistics are summed about a pivot — the tile's first row (always a valid pixel) — so fp32 is enough
+  // inside the tile; the plain sums are rebuilt in fp64 before they go to the slab (common.h)
+  if ((EPI & 2) && MODE != 1) unpack8(*reinterpret_cast<const u32x4*>(Os + oc * 16), kf);
 #pragma unroll
   for (int pass = 0; pass < RBM / RPP; ++pass) {
     const int row = orow0 + pass * RPP;
@@ -118,27 +121,45 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
         float f[8];
         unpack8(v, f);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+        for (int q = 0; q < 8; ++q) { const float d = f[q] - kf[q]; s1[q] += d; s2[q] += d * d; }
       }
     }
   }
   if (EPI & 2) {
-    static_assert(RBM * OPITCH <= LDS_BYTES && RPP * 2 * BN * 4 <= LDS_BYTES, "epilogue must fit in the ring");
+    static_assert(RBM * OPITCH <= LDS_BYTES && (RPP * 2 + 1) * BN * 4 <= LDS_BYTES, "epilogue must fit in the ring");
     __syncthreads();                                                // the output tile has been read out
-    float* const red = reinterpret_cast<float*>(smem);              // [RPP][2][BN], over the output tile
+    float* const red = reinterpret_cast<float*>(smem);              // [RPP][2][BN] + pivots [BN], over the output tile
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
       red[(orow0 * 2 + 1) * BN + oc * 8 + q] = s2[q];
     }
+    if (MODE != 1 && orow0 == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) red[RPP * 2 * BN + oc * 8 + q] = kf[q];
+    }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid - which * BN;
-      float s = 0.f;
+    const size_t sbase = (size_t)(tile_m % DDL_BN_SLOTS) * 2;
+    if (MODE == 1) {
+      if (tid < 2 * BN) {
+        const int which = tid / BN, col = tid - which * BN;
+        float s = 0.f;
 #pragma unroll 4
-      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
-      if (n0 + col < p.OC)
-        atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
+        for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
+        if (n0 + col < p.OC) slab_add(p.stats, (sbase + which) * (size_t)p.OC + n0 + col, (double)s);
+      }
+    } else if (tid < BN) {
+      const int col = tid;
+      float a = 0.f, b = 0.f;
+#pragma unroll 4
+      for (int g = 0; g < RPP; ++g) { a += red[(g * 2) * BN + col]; b += red[(g * 2 + 1) * BN + col]; }
+      if (n0 + col < p.OC) {
+        const int nrows = min(RBM, p.M - m0);
+        double sx, sxx;
+        unshift_sums(a, b, red[RPP * 2 * BN + col], (double)nrows, sx, sxx);
+        slab_add(p.stats, sbase * (size_t)p.OC + n0 + col, sx);
+        slab_add(p.stats, (sbase + 1) * (size_t)p.OC + n0 + col, sxx);
+      }
     }
   }
 }

@@ -205,9 +205,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int RPP = 256 / CPR;    // rows per pass
   const int oc = tid % CPR, orow0 = tid / CPR;
   const int ncol = n0 + oc * 8;
-  float s1[8], s2[8];
+  float s1[8], s2[8], kf[8];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; }
+  for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; kf[q] = 0.f; }
+  if (p.stats != nullptr) unpack8(*reinterpret_cast<const u32x4*>(Os + oc * 16), kf);     // pivot: the tile's first row
 #pragma unroll
   for (int pass = 0; pass < BM / RPP; ++pass) {
     const int row = orow0 + pass * RPP;
@@ -252,26 +253,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         float f[8];
         unpack8(v, f);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { s1[q] += f[q]; s2[q] += f[q] * f[q]; }
+        for (int q = 0; q < 8; ++q) { const float d = f[q] - kf[q]; s1[q] += d; s2[q] += d * d; }
       }
     }
   }
   if (p.stats != nullptr) {
     constexpr int OS_BYTES = ((BM * OPITCH + 15) / 16) * 16;
-    float* const red = reinterpret_cast<float*>(smem + OS_BYTES);   // [RPP][2][BN]
+    float* const red = reinterpret_cast<float*>(smem + OS_BYTES);   // [RPP][2][BN] + pivots [BN]
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       red[(orow0 * 2 + 0) * BN + oc * 8 + q] = s1[q];
       red[(orow0 * 2 + 1) * BN + oc * 8 + q] = s2[q];
     }
+    if (orow0 == 0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) red[RPP * 2 * BN + oc * 8 + q] = kf[q];
+    }
     __syncthreads();
-    if (tid < 2 * BN) {
-      const int which = tid / BN, col = tid - which * BN;
-      float s = 0.f;
+    if (tid < BN) {
+      const int col = tid;
+      float a = 0.f, b = 0.f;
 #pragma unroll 4
-      for (int g = 0; g < RPP; ++g) s += red[(g * 2 + which) * BN + col];
-      if (n0 + col < p.OC)
-        atomicAdd(&p.stats[((size_t)(tile_m % DDL_BN_SLOTS) * 2 + which) * (size_t)p.OC + n0 + col], s);
+      for (int g = 0; g < RPP; ++g) { a += red[(g * 2) * BN + col]; b += red[(g * 2 + 1) * BN + col]; }
+      if (n0 + col < p.OC) {
+        const int nrows = min(BM, p.M - m0);
+        double sx, sxx;
+        unshift_sums(a, b, red[RPP * 2 * BN + col], (double)nrows, sx, sxx);
+        const size_t sbase = (size_t)(tile_m % DDL_BN_SLOTS) * 2;
+        slab_add(p.stats, sbase * (size_t)p.OC + n0 + col, sx);
+        slab_add(p.stats, (sbase + 1) * (size_t)p.OC + n0 + col, sxx);
+      }
     }
   }
 }

@@ -20,7 +20,7 @@ class LSTMRef(tnn.Module):
         self.conv = tnn.Conv1d(history, 64, 1)
         self.lstms = tnn.ModuleList(
             dnn.LSTM(features if i == 0 else hidden_params, hidden_params, batch_first=True) for i in range(hidden_layers))
-        self.fc = tnn.Linear(hidden_params, classes)
+        self.fc = dnn.Linear(hidden_params, classes)
 
     def _front(self, x):
         # conv+ReLU, MaxPool1d(1)+ReLU == ReLU.  A kernel-size-1 Conv1d is a Linear over the channel axis: computed as

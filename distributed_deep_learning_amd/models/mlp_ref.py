@@ -22,9 +22,16 @@ class MLPRef(tnn.Module):
         dims = [input_size] + [hidden_size] * (hidden_layers + 1)
         self.hidden = tnn.ModuleList(dnn.Linear(a, b) for a, b in zip(dims[:-1], dims[1:]))
         self.out = dnn.Linear(hidden_size, classes)
+        # the reference ends in Softmax, or in Sigmoid when classes < 2 (MLP/model.py:59).  The Softmax in front of
+        # CrossEntropyLoss is defect A5 (this model emits logits); the single-output Sigmoid head is kept.
+        self.sigmoid_head = classes < 2
+
+    def _head(self, x):
+        y = self.out(x)
+        return torch.sigmoid(y.float()) if self.sigmoid_head else y
 
     def stages(self):
-        return [lambda x, l=l: l(x, relu=True) for l in self.hidden] + [self.out]
+        return [lambda x, l=l: l(x, relu=True) for l in self.hidden] + [self._head]
 
     def stage_modules(self):
         from ..parallel.mp import FnStage
@@ -39,7 +46,8 @@ class MLPRef(tnn.Module):
             params = []
             for l in layers:
                 params += [l.weight, l.bias]
-            return _F.FusedMLP.apply(x, False, *params)
+            y = _F.FusedMLP.apply(x, False, *params)
+            return torch.sigmoid(y) if self.sigmoid_head else y
         for s in self.stages():
             x = s(x)
         return x

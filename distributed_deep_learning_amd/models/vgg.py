@@ -1,8 +1,8 @@
 """VGG-16 (configuration D) with torchvision-compatible keys (``features.N.weight``, ``classifier.N.weight``).
 
 North-star config 4: 138 M parameters -> a 553 MB fp32 gradient, the bandwidth-bound xGMI all-reduce case.  Every
-conv runs with bias + ReLU fused into the implicit-GEMM epilogue; the three classifier GEMMs are plain library
-GEMMs (hipBLASLt via torch).  ``batch_norm=True`` gives VGG-16-BN using the fused conv+BN+ReLU unit.
+conv runs with bias + ReLU fused into the implicit-GEMM epilogue; the three classifier layers run on the framework's
+own split-M MFMA GEMM with bias + ReLU + dropout fused around it (``nn.functional.LinearAct``).  ``batch_norm=True`` gives VGG-16-BN using the fused conv+BN+ReLU unit.
 """
 from __future__ import annotations
 
@@ -75,6 +75,26 @@ class VGG(tnn.Module):
                 i += 1
         return x
 
+    def _classifier(self, x):
+        """``classifier`` with every Linear -> ReLU -> Dropout run fused into one unit (the Sequential stays the
+        parameter container, so the torchvision keys ``classifier.0/3/6`` are unchanged)."""
+        mods = list(self.classifier)
+        if not x.is_cuda:
+            return self.classifier(x)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, dnn.Linear):
+                relu = i + 1 < len(mods) and isinstance(mods[i + 1], (dnn.ReLU, tnn.ReLU))
+                j = i + 2 if relu else i + 1
+                drop = mods[j].p if j < len(mods) and isinstance(mods[j], tnn.Dropout) else 0.0
+                x = m(x, relu=relu, dropout=drop)
+                i = j + (1 if drop or (j < len(mods) and isinstance(mods[j], tnn.Dropout)) else 0)
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def stages(self):
         """Five conv blocks (split after each max-pool) + classifier, for inter-layer partitioning."""
         cuts, mods = [0], list(self.features)
@@ -84,7 +104,7 @@ class VGG(tnn.Module):
         st = []
         for a, b in zip(cuts[:-1], cuts[1:]):
             st.append(lambda x, a=a, b=b: self._features(to_device_input(x) if a == 0 else x, a, b))
-        st.append(lambda x: self.classifier(self.flatten(x)))
+        st.append(lambda x: self._classifier(self.flatten(x)))
         return st
 
     def stage_modules(self):
@@ -101,7 +121,7 @@ class VGG(tnn.Module):
     def forward(self, x):
         x = to_device_input(x)
         x = self._features(x)
-        return self.classifier(self.flatten(x))
+        return self._classifier(self.flatten(x))
 
 
 def vgg16(num_classes=1000, **kw):

@@ -1,7 +1,7 @@
 """Layers and fused functional units (GPU path = hand-written gfx950 kernels)."""
-from .modules import (AvgPool2d, BatchNorm2d, Conv2d, Flatten, GlobalAvgPool2d, Linear, MaxPool2d, ReLU,
+from .modules import (AvgPool2d, BatchNorm2d, Conv2d, Flatten, GlobalAvgPool2d, L1Loss, Linear, MaxPool2d, ReLU,
                       SoftmaxCrossEntropyLoss, conv_bn_act, residual_block, to_device_input)
 from .rnn import LSTM
 
-__all__ = ["AvgPool2d", "BatchNorm2d", "Conv2d", "Flatten", "GlobalAvgPool2d", "LSTM", "Linear", "MaxPool2d", "ReLU",
-           "SoftmaxCrossEntropyLoss", "conv_bn_act", "residual_block", "to_device_input"]
+__all__ = ["AvgPool2d", "BatchNorm2d", "Conv2d", "Flatten", "GlobalAvgPool2d", "L1Loss", "LSTM", "Linear", "MaxPool2d",
+           "ReLU", "SoftmaxCrossEntropyLoss", "conv_bn_act", "residual_block", "to_device_input"]

@@ -587,27 +587,108 @@ class ReLU(torch.autograd.Function):
         return K.relu_bwd(_bf16(dy), y)
 
 
-class Linear(torch.autograd.Function):
-    """bf16 GEMM on hipBLASLt (a plain library GEMM) against the cached bf16 copy of the fp32 master weight."""
+class LinearAct(torch.autograd.Function):
+    """``y = dropout(relu(x @ W^T + b))`` with all three GEMMs on the hand-written split-M MFMA kernel
+    (``ops.kernels.gemm_tn``; see ``csrc/linear.hip`` for why that kernel and how the operands are laid out), bias /
+    ReLU / dropout in the epilogue kernel, ReLU+dropout gate and bias gradient in ONE backward pass, and the weight
+    gradient accumulated straight into the arena on the side stream.
+
+    ``w16`` bf16 ``[out_p, in_p]`` and ``w16_t`` bf16 ``[in_p, out_p]`` are the (8-padded) weight and its transpose —
+    the arena's shadow pair when the parameter lives there.  No dropout mask is stored: a kept, live element is one
+    with ``y > 0``.  Reference: every model of the reference ends in ``nn.Linear``
+    (``/root/reference/src/pytorch/CNN/model.py:183``, ``MLP/model.py:51-58``, ``LSTM/model.py:94``)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_bf16):
-        x = _bf16(x)
-        ctx.save_for_backward(x, w_bf16)
-        ctx.has_bias = bias is not None
-        y = x @ w_bf16.t()
-        if bias is not None:
-            y = y + bias.to(BF16)
-        return y
+    def forward(ctx, x, weight, bias, w16, w16_t, bias_p, relu, drop_p):
+        B, fin = x.shape
+        out_f = weight.shape[0]
+        out_p, in_p = w16.shape
+        Bp = (B + 7) // 8 * 8
+        if x.dtype not in (BF16, torch.float32) or x.stride(1) != 1:
+            x = x.to(BF16).contiguous()
+        if fin != in_p:                                    # feature count not a multiple of 8 (LeNet's 84): zero columns
+            x = torch.nn.functional.pad(x, (0, in_p - fin))
+        xt = K.transpose_pad(x, Bp)                        # [in_p, Bp]: the reduction index leads
+        acc = torch.zeros((Bp, out_p), dtype=torch.float32, device=x.device)
+        K.gemm_tn(xt, w16_t, acc)
+        y = K.linear_epilogue(acc, bias_p, Bp, relu=relu, drop_p=drop_p)
+        need_w = ctx.needs_input_grad[1]
+        xs = None
+        if need_w:                                         # wgrad operand: bf16 [Bp, in_p], batch rows zero-padded
+            xs = x if (x.dtype == BF16 and x.is_contiguous() and Bp == B) else \
+                torch.nn.functional.pad(x.to(BF16), (0, 0, 0, Bp - B)).contiguous()
+        gated = relu or drop_p > 0.0
+        ctx.save_for_backward(xs, y if gated else None, w16)
+        ctx.meta = (B, fin, out_f, gated, 1.0 / (1.0 - drop_p) if drop_p > 0.0 else 1.0)
+        ctx.weight, ctx.bias = weight, bias
+        return y if (Bp == B and out_p == out_f) else y[:B, :out_f]
 
     @staticmethod
     def backward(ctx, dy):
-        x, w_bf16 = ctx.saved_tensors
+        xs, y, w16 = ctx.saved_tensors
+        B, fin, out_f, gated, scale = ctx.meta
+        out_p, in_p = w16.shape
+        weight, bias = ctx.weight, ctx.bias
         dy = _bf16(dy)
-        dx = dy @ w_bf16 if ctx.needs_input_grad[0] else None
-        dw = (dy.t() @ x).float()
-        db = dy.float().sum(0) if ctx.has_bias else None
-        return dx, dw, db, None
+        Bp = (B + 7) // 8 * 8
+        if Bp != B or out_p != out_f:
+            dy = torch.nn.functional.pad(dy, (0, out_p - out_f, 0, Bp - B))
+        dy = dy.contiguous()
+        # gate (ReLU / dropout) + bias gradient in one pass; the bias gradient goes straight into the arena when it can
+        db = None
+        has_bias = bias is not None and ctx.needs_input_grad[2]
+        arena_b = getattr(bias, "_ddl_arena", None) if has_bias else None
+        direct_b = (arena_b is not None and out_p == out_f and arena_b.grad_is_arena_view(bias) and bias.grad.is_contiguous())
+        if gated or has_bias or scale != 1.0:
+            g, dbv = K.linear_bwd_gate(dy, y if gated else None, scale, grad_out=bias.grad if direct_b else None,
+                                       want_bias=has_bias, want_g=gated or scale != 1.0)
+            if g is None:
+                g = dy
+            if has_bias:
+                if direct_b:
+                    arena_b.notify_grad_ready(bias)
+                else:
+                    db = dbv[:out_f]
+        else:
+            g = dy
+        dx = None
+        if ctx.needs_input_grad[0]:
+            gt = K.transpose_pad(g, Bp)                    # [out_p, Bp]
+            acc = torch.zeros((Bp, in_p), dtype=torch.float32, device=g.device)
+            K.gemm_tn(gt, w16, acc)
+            dx = K.cast_rows(acc, B, in_p)
+            if in_p != fin:
+                dx = dx[:, :fin]
+        dw = None
+        if ctx.needs_input_grad[1]:
+            arena = getattr(weight, "_ddl_arena", None)
+            if (arena is not None and out_p == out_f and in_p == fin and arena.grad_is_arena_view(weight)
+                    and weight.grad.is_contiguous()):
+                with streams.fork(g, xs):                  # side stream: overlaps the rest of backward
+                    K.gemm_tn(g, xs, weight.grad)
+                arena.notify_grad_ready(weight)
+            else:
+                acc = torch.zeros((out_p, in_p), dtype=torch.float32, device=g.device)
+                K.gemm_tn(g, xs, acc)
+                dw = acc[:out_f, :fin]
+        return dx, dw, db, None, None, None, None, None
+
+
+class L1Loss(torch.autograd.Function):
+    """Mean absolute error with the gradient produced in the forward launch (``csrc/linear.hip``): the reference's
+    LSTM criterion, ``/root/reference/src/pytorch/LSTM/main.py:163``."""
+
+    @staticmethod
+    def forward(ctx, pred, target):
+        out, grad = K.l1_loss(pred, target, want_grad=ctx.needs_input_grad[0])
+        ctx.save_for_backward(grad)
+        ctx.pred_dtype = pred.dtype
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gloss):
+        (grad,) = ctx.saved_tensors
+        return (grad * gloss).to(ctx.pred_dtype), None
 
 
 class SoftmaxCrossEntropy(torch.autograd.Function):

@@ -325,29 +325,63 @@ class GlobalAvgPool2d(tnn.Module):
 
 
 class Linear(tnn.Linear):
-    """GPU path: bf16 hipBLASLt GEMM against a cached bf16 copy of the fp32 master weight."""
+    """Fully connected layer.  GPU path: :class:`functional.LinearAct` — forward, input-gradient and weight-gradient
+    GEMMs on the hand-written split-M MFMA kernel, bias / ReLU / dropout fused around them:
+    ``lin(x, relu=True, dropout=0.5)``.  Feature counts that are not multiples of 8 are zero-padded internally."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._pack = None
+        self._bias_pack = None
 
-    def _w16(self):
+    def packed(self):
+        """(bf16 ``[out_p, in_p]``, bf16 ``[in_p, out_p]``): the arena's shadow pair, or a cached private copy."""
         w = self.weight
+        sh_t = getattr(w, "_ddl_shadow_t", None)
+        if sh_t is not None and getattr(w, "_ddl_shadow_version", -1) == w._version:
+            return w._ddl_shadow, sh_t
         key = (w._version, _state.weights_epoch(), w.data_ptr(), w.device)
         if self._pack is None or self._pack[0] != key:
-            self._pack = (key, w.detach().to(BF16))
-        return self._pack[1]
+            with torch.no_grad():
+                src = w.detach()
+                o, i = src.shape
+                if o % 8 or i % 8:
+                    src = TF.pad(src, (0, _pad8(i) - i, 0, _pad8(o) - o))
+                w16 = src.to(BF16).contiguous()
+                self._pack = (key, w16, K.transpose_pad(w16, w16.shape[0]))
+        return self._pack[1], self._pack[2]
 
-    def forward(self, x, relu: bool = False):
+    def _kernel_bias(self):
+        b = self.bias
+        if b is None or self.out_features % 8 == 0:
+            return b
+        key = (b._version, _state.weights_epoch(), b.data_ptr())
+        if self._bias_pack is None or self._bias_pack[0] != key:
+            self._bias_pack = (key, TF.pad(b.detach().float(), (0, _pad8(self.out_features) - self.out_features)))
+        return self._bias_pack[1]
+
+    def forward(self, x, relu: bool = False, dropout: float = 0.0):
         if not x.is_cuda:
             y = super().forward(x)
-        else:
-            if x.dim() > 2:
-                x = x.reshape(x.shape[0], -1)
-            y = F.Linear.apply(x, self.weight, self.bias, self._w16())
-        if relu:
-            y = F.ReLU.apply(y) if (y.is_cuda and y.numel() % 8 == 0) else TF.relu(y)
-        return y
+            if relu:
+                y = TF.relu(y)
+            return TF.dropout(y, dropout, self.training) if dropout > 0.0 else y
+        if x.dim() != 2:
+            x = x.reshape(-1, x.shape[-1]) if x.dim() == 3 else x.reshape(x.shape[0], -1)
+        w16, w16_t = self.packed()
+        return F.LinearAct.apply(x, self.weight, self.bias, w16, w16_t, self._kernel_bias(), relu,
+                                 float(dropout) if self.training else 0.0)
+
+
+class L1Loss(tnn.Module):
+    """Mean absolute error (the reference's LSTM criterion); GPU path = one fused forward+gradient launch."""
+
+    last_correct = None
+
+    def forward(self, out, target):
+        if out.is_cuda:
+            return F.L1Loss.apply(out, target)
+        return TF.l1_loss(out.float(), target.float())
 
 
 class Flatten(tnn.Module):

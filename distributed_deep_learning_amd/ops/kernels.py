@@ -56,10 +56,22 @@ def filter_repack(w: torch.Tensor, want_copy: bool = True):
 
 
 def new_slab(channels: int, device) -> torch.Tensor:
-    """A zeroed ``[slots, 2, C]`` reduction slab.  Slabs are self-cleaning (the finalize kernels re-zero them), so
+    """A zeroed reduction slab: ``[slots, 2, C]`` fp64 sums (``csrc/common.h``: the variance subtraction needs them)
+    held in an fp32 tensor of ``2*slots + 2`` rows.  Slabs are self-cleaning (the finalize kernels re-zero them), so
     one can be kept per layer and reused every step without a memset."""
-    # two extra rows: scratch for the three per-channel coefficient vectors of the backward pass (never folded)
-    return torch.zeros((_lib.bn_slots() + 2, 2, channels), dtype=torch.float32, device=device)
+    # two extra fp32 rows: scratch for the three per-channel coefficient vectors of the backward pass (never folded)
+    return torch.zeros((2 * _lib.bn_slots() + 2, 2, channels), dtype=torch.float32, device=device)
+
+
+def _slab_scratch(slab: torch.Tensor, channels: int) -> int:
+    """Device address of the slab's fp32 scratch rows (behind the fp64 sums)."""
+    return slab.data_ptr() + _lib.bn_slots() * 2 * channels * 8
+
+
+def slab_sums(slab: torch.Tensor) -> torch.Tensor:
+    """Totals ``[2, C]`` (fp32) of a reduction slab that has not been folded yet (tests / debugging)."""
+    n = _lib.bn_slots()
+    return slab[:2 * n].reshape(-1).view(torch.float64).view(n, 2, -1).sum(0).float()
 
 
 def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=False, slab=None):
@@ -255,7 +267,7 @@ def bn_backward(dy, mask, x, gamma, mean, invstd, relu=True, want_dres=False, sl
         if presummed:
             raise ValueError("bn_backward: presummed needs the slab the sums were accumulated into")
         slab = new_slab(Cc, x.device)
-    coef = slab.data_ptr() + _lib.bn_slots() * 2 * Cc * 4        # the slab's scratch rows
+    coef = _slab_scratch(slab, Cc)
     check(lib.ddl_bn_backward(ptr(dy), ptr(mask) if relu else None, ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx),
                               ptr(dres), ptr(dgb[0]), ptr(dgb[1]), ptr(slab), ptr(coef), N * H * W, Cc, int(relu),
                               int(grad_out is not None), int(presummed), stream_ptr()), "bn_backward")
@@ -298,7 +310,7 @@ def bn_backward_pair(dy, mask, xa, xb, stat_a, stat_b, relu=True, slabs=None, gr
         t = torch.empty((4, Cc), dtype=torch.float32, device=xa.device)
         ga, gb = (t[0], t[1]), (t[2], t[3])
     sa, sb = slabs if slabs is not None else (new_slab(Cc, xa.device), new_slab(Cc, xa.device))
-    scratch = _lib.bn_slots() * 2 * Cc * 4
+    scratch = _lib.bn_slots() * 2 * Cc * 8
     check(lib.ddl_bn_backward_pair(ptr(dy), ptr(mask) if relu else None, ptr(xa), ptr(xb),
                                    ptr(stat_a[0]), ptr(stat_a[1]), ptr(stat_a[2]),
                                    ptr(stat_b[0]), ptr(stat_b[1]), ptr(stat_b[2]), ptr(dxa), ptr(dxb),
@@ -347,7 +359,7 @@ def bn_relu_maxpool_bwd(dp, idx, x, gamma, mean, invstd, k, stride, pad, slab=No
         dg, db = both[0], both[1]
     if slab is None:
         slab = new_slab(Cc, x.device)
-    coef = slab.data_ptr() + _lib.bn_slots() * 2 * Cc * 4
+    coef = _slab_scratch(slab, Cc)
     check(lib.ddl_bn_relu_maxpool_bwd(ptr(dp), ptr(idx), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
                                       ptr(db), ptr(slab), coef, N, H, W, Cc, P, Q, k, stride, pad,
                                       int(grad_out is not None), stream_ptr()), "bn_relu_maxpool_bwd")
@@ -551,6 +563,118 @@ def s2d_filter(w: torch.Tensor) -> torch.Tensor:
     w8 = w8.reshape(K_, 3, 4, 2, 4, 2).permute(0, 3, 5, 1, 2, 4)        # [K, p, q, c, a, b]
     w12 = w8.reshape(K_, 12, 4, 4)
     return torch.nn.functional.pad(w12, (0, 0, 0, 0, 0, 4))             # [K,16,4,4]
+
+
+# ----------------------------------------------------------------------------------------------- linear (fc) layers
+def _pad8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """``out[Ka, Cb] += a[M, Ka]^T @ b[M, Cb]`` — bf16 operands with the REDUCTION index slowest, fp32 accumulation into
+    ``out`` (contiguous; zero it for a plain product).  Runs on the split-M MFMA kernel of ``csrc/conv_wgrad.hip``
+    (a filter gradient with 1x1 taps IS this GEMM), which spreads the reduction over the whole chip."""
+    lib = _lib.require()
+    _chk_act(a, "gemm_tn")
+    _chk_act(b, "gemm_tn")
+    M, Ka = a.shape
+    M2, Cb = b.shape
+    if M2 != M or Ka % 8 or Cb % 8 or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("gemm_tn: operands must be contiguous [M, Ka] / [M, Cb] with Ka, Cb multiples of 8")
+    if out.dtype != torch.float32 or tuple(out.shape) != (Ka, Cb) or not out.is_contiguous():
+        raise ValueError("gemm_tn: out must be a contiguous fp32 [Ka, Cb] tensor")
+    check(lib.ddl_conv_wgrad(ptr(a), ptr(b), ptr(out), M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0, stream_ptr()), "gemm_tn")
+    return out
+
+
+def transpose_pad(x: torch.Tensor, rows_padded: int | None = None) -> torch.Tensor:
+    """``[R, C]`` (bf16 or fp32, rows ``C``-contiguous) -> bf16 ``[C, Rp]`` with columns ``R..Rp-1`` zero."""
+    lib = _lib.require()
+    R, Cc = x.shape
+    if x.stride(1) != 1 or x.dtype not in (BF16, torch.float32):
+        raise ValueError("transpose_pad: need a bf16 / fp32 matrix with contiguous rows")
+    _lib.check_device(x, "transpose_pad")
+    Rp = _pad8(R) if rows_padded is None else rows_padded
+    out = torch.empty((Cc, Rp), dtype=BF16, device=x.device)
+    check(lib.ddl_transpose_pad(ptr(x), int(x.dtype == torch.float32), ptr(out), R, Cc, Rp, x.stride(0), stream_ptr()),
+          "transpose_pad")
+    return out
+
+
+_RNG_STATE: dict = {}
+
+
+def rng_state(device) -> torch.Tensor:
+    """Device-resident ``[seed, counter]`` of the dropout generator (seeded from ``torch.initial_seed()`` on first use;
+    the kernels advance the counter themselves, so captured graphs draw fresh masks on every replay)."""
+    key = (device.type, device.index)
+    st = _RNG_STATE.get(key)
+    if st is None:
+        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+    return st
+
+
+def linear_epilogue(acc: torch.Tensor, bias, rows: int, relu: bool = False, drop_p: float = 0.0) -> torch.Tensor:
+    """fp32 accumulator ``[Mp, N]`` -> bf16 ``[rows, N]``: ``drop(relu(acc + bias))`` (``csrc/linear.hip``)."""
+    lib = _lib.require()
+    Mp, N = acc.shape
+    if acc.dtype != torch.float32 or not acc.is_contiguous() or N % 8 or rows > Mp:
+        raise ValueError("linear_epilogue: acc must be a contiguous fp32 [Mp, N] tensor with N % 8 == 0")
+    if bias is not None and (bias.dtype != torch.float32 or bias.numel() != N or not bias.is_contiguous()):
+        raise ValueError("linear_epilogue: bias must be a contiguous fp32 [N] tensor")
+    _lib.check_device(acc, "linear_epilogue")
+    y = torch.empty((rows, N), dtype=BF16, device=acc.device)
+    st = rng_state(acc.device) if drop_p > 0.0 else None
+    check(lib.ddl_linear_epilogue(ptr(acc), ptr(bias), ptr(y), rows, N, int(relu), float(drop_p), ptr(st), stream_ptr()),
+          "linear_epilogue")
+    return y
+
+
+def linear_bwd_gate(dy: torch.Tensor, y, scale: float = 1.0, grad_out=None, want_bias: bool = True, want_g: bool = True):
+    """``g = dy * [y > 0] * scale`` (``y`` given: ReLU and / or dropout gate) or ``dy * scale``; the bias gradient
+    ``sum_rows g`` goes to a fresh fp32 ``[C]`` tensor or is ACCUMULATED into ``grad_out``.  Returns ``(g, db)``."""
+    lib = _lib.require()
+    _chk_act(dy, "linear_bwd_gate")
+    M, Cc = dy.shape
+    if not dy.is_contiguous() or Cc % 8 or (y is not None and (y.shape != dy.shape or not y.is_contiguous())):
+        raise ValueError("linear_bwd_gate: dy / y must be contiguous [M, C] with C % 8 == 0")
+    g = torch.empty_like(dy) if want_g else None
+    db = None
+    if want_bias:
+        if grad_out is not None:
+            if grad_out.dtype != torch.float32 or grad_out.numel() != Cc or not grad_out.is_contiguous():
+                raise ValueError("linear_bwd_gate: grad_out must be a contiguous fp32 [C] tensor")
+            db = grad_out
+        else:
+            db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+    check(lib.ddl_linear_bwd_gate(ptr(dy), ptr(y), ptr(g), ptr(db), M, Cc, float(scale), int(grad_out is not None),
+                                  stream_ptr()), "linear_bwd_gate")
+    return g, db
+
+
+def cast_rows(acc: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
+    """fp32 ``[Mp, Np]`` accumulator -> bf16 ``[rows, cols]`` (drops the padding; ``cols % 8 == 0``)."""
+    lib = _lib.require()
+    if acc.dtype != torch.float32 or not acc.is_contiguous() or cols % 8 or rows > acc.shape[0] or cols > acc.shape[1]:
+        raise ValueError("cast_rows: bad shapes")
+    out = torch.empty((rows, cols), dtype=BF16, device=acc.device)
+    check(lib.ddl_cast_rows(ptr(acc), ptr(out), rows, cols, acc.shape[1], stream_ptr()), "cast_rows")
+    return out
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
+    """Mean absolute error: returns ``(loss fp32 [1], grad fp32 like pred or None)`` with ``grad = sign(p - t) / n``."""
+    lib = _lib.require()
+    pred = pred.contiguous()
+    target = target.to(torch.float32).contiguous()
+    if pred.dtype not in (BF16, torch.float32) or target.numel() != pred.numel():
+        raise ValueError("l1_loss: pred must be bf16 / fp32 and match the target's size")
+    _lib.check_device(pred, "l1_loss")
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    grad = torch.empty(pred.shape, dtype=torch.float32, device=pred.device) if want_grad else None
+    check(lib.ddl_l1_loss(ptr(pred), int(pred.dtype == BF16), ptr(target), ptr(grad), ptr(out), pred.numel(), stream_ptr()),
+          "l1_loss")
+    return out, grad
 
 
 # ----------------------------------------------------------------------------------------------- fused small MLP

@@ -139,15 +139,23 @@ class ParamArena:
     # ------------------------------------------------------------------ conv filter repacks (one launch per step)
     def _build_repack_table(self) -> None:
         """Descriptor table for ``csrc/eltwise.hip::filter_transpose_batched_kernel``: every 4-D parameter stored
-        channels-last (physically KRSC) with C % 8 == 0 and K % 8 == 0 gets a CRSK twin at the same arena offset."""
+        channels-last (physically KRSC) with C % 8 == 0 and K % 8 == 0 gets a CRSK twin at the same arena offset, and
+        every contiguous 2-D (Linear) weight ``[out, in]`` with both sides % 8 == 0 an ``[in, out]`` twin (a 1x1 filter)."""
         import numpy as np
         dt = np.dtype([("in_off", "<i8"), ("out_off", "<i8"), ("K", "<i4"), ("RS", "<i4"), ("C", "<i4"),
                        ("tile_begin", "<i4"), ("tiles_c", "<i4"), ("tiles_k", "<i4")])
+        def geom(p):
+            if p.dim() == 4 and not (p.shape[1] % 8 or p.shape[0] % 8) and p.permute(0, 2, 3, 1).is_contiguous():
+                return p.shape
+            if p.dim() == 2 and not (p.shape[1] % 8 or p.shape[0] % 8) and p.is_contiguous():
+                return (p.shape[0], p.shape[1], 1, 1)
+            return None
+
         rows, tile = [], 0
         for p, s in zip(self.params, self.segments):
-            if p.dim() != 4 or p.shape[1] % 8 or p.shape[0] % 8 or not p.permute(0, 2, 3, 1).is_contiguous():
+            if geom(p) is None:
                 continue
-            K_, C_, R_, S_ = p.shape
+            K_, C_, R_, S_ = geom(p)
             tc, tk = (C_ + 31) // 32, (K_ + 31) // 32
             rows.append((s.offset, s.offset, K_, R_ * S_, C_, tile, tc, tk))
             tile += R_ * S_ * tc * tk
@@ -159,9 +167,10 @@ class ParamArena:
         descs = torch.from_numpy(arr.view(np.uint8).copy()).to(self.device)
         self._repack = (descs, len(rows), tile)
         for p, s in zip(self.params, self.segments):
-            if p.dim() == 4 and not (p.shape[1] % 8 or p.shape[0] % 8) and p.permute(0, 2, 3, 1).is_contiguous():
-                K_, C_, R_, S_ = p.shape
-                p._ddl_shadow_t = self.shadow_t[s.offset:s.offset + s.numel].view(C_, R_, S_, K_)   # noqa: SLF001
+            if geom(p) is not None:
+                K_, C_, R_, S_ = geom(p)
+                twin = self.shadow_t[s.offset:s.offset + s.numel]
+                p._ddl_shadow_t = twin.view(C_, R_, S_, K_) if p.dim() == 4 else twin.view(C_, K_)   # noqa: SLF001
 
     def refresh_transposes(self) -> None:
         if self._repack is not None:

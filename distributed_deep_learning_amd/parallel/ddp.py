@@ -172,7 +172,9 @@ class DistributedDataParallel(tnn.Module):
         self.arena = arena
         self.backend = td.get_backend(self.pg) if self.dist else "none"
         self.on_gpu = arena.device.type == "cuda"
-        self.staged = self.backend == "gloo" and self.on_gpu       # gloo over GPU tensors: host staging (see module doc)
+        # gloo over GPU tensors: host staging (see module doc); DDL_GLOO_GPU_DIRECT=1 hands the GPU tensors to gloo itself
+        # (the configuration that hung in round 1 - kept for bench/ddp_gloo_gpu.py --transport gloo-gpu)
+        self.staged = self.backend == "gloo" and self.on_gpu and os.environ.get("DDL_GLOO_GPU_DIRECT", "0") != "1"
         if grad_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be None / torch.float32 (in place) or torch.bfloat16")
         self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None

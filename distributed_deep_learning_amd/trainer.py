@@ -25,7 +25,7 @@ from .data import BatchLoader, ShardedSampler, WindowDataset, split_indices
 from .data import synthetic as syn
 from .metrics import (JsonlLogger, PhaseMeter, StepTimer, fmt_test_end, fmt_train_begin, fmt_train_end, fmt_val_end,
                       now_ts)
-from .nn import SoftmaxCrossEntropyLoss
+from .nn import L1Loss, SoftmaxCrossEntropyLoss
 from .optim import LARS, FusedAdam, FusedSGD, StepLR
 from .parallel import DistributedDataParallel, ParamArena, PipelinedModel, StagedModel
 
@@ -61,13 +61,6 @@ def _model_kwargs(cfg: Config) -> dict:
     if cfg.classes is not None and m not in ("lstm", "lstm_ref", "cnn", "densenet_ref", "mlp", "mlp_ref"):
         kw["num_classes"] = cfg.classes
     return kw
-
-
-class _L1(tnn.Module):
-    last_correct = None
-
-    def forward(self, out, target):
-        return torch.nn.functional.l1_loss(out.float(), target.float())
 
 
 # Workloads whose step is launch-bound (hundreds of microsecond-kernels): with ``--graph auto`` (the default) a
@@ -154,7 +147,7 @@ class Trainer:
 
         wl = WORKLOADS.get(cfg.model)
         loss_kind = cfg.loss or (wl[1] if wl else "xent")
-        self.criterion = SoftmaxCrossEntropyLoss() if loss_kind == "xent" else _L1()
+        self.criterion = SoftmaxCrossEntropyLoss() if loss_kind == "xent" else L1Loss()
         opt_kind = cfg.optimizer if (cfg.optimizer != "sgd" or wl is None) else wl[2]
         self.optimizers = []
         for a in self.arenas:

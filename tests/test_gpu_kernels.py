@@ -63,7 +63,7 @@ def test_conv_fwd_dgrad_wgrad(case):
     y_ref = F.conv2d(x.float(), wq, None, stride, pad)
     _close(y, y_ref, what="conv fwd")
     # fused BN partial sums are computed from the rounded bf16 outputs
-    s = stats.sum(0)
+    s = K.slab_sums(stats)
     yf = y.float()
     _close(s[0], yf.sum((0, 2, 3)), rtol=1e-3, atol=1e-2 * max(1.0, yf.abs().max().item()), what="fused sum")
     _close(s[1], (yf * yf).sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="fused sumsq")
@@ -328,7 +328,7 @@ for (N, C, H, W, Kc) in [(2, 64, 56, 56, 64), (3, 256, 14, 14, 256), (1, 32, 20,
     y, st = K.conv2d_fwd(x, wk, 1, 1, want_stats=True)
     ref = F.conv2d(x.float(), wq, None, 1, 1)
     assert (y.float() - ref).abs().max().item() < 2e-2 + 2e-2 * ref.abs().max().item()
-    s = st.sum(0)
+    s = K.slab_sums(st)
     assert torch.allclose(s[0], y.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-1)
     dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
     add = torch.randn(x.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
@@ -503,7 +503,7 @@ def test_dgrad_epilogue_bn_backward_sums(case):
     dx = K.conv2d_dgrad(dy, w, (H, W), stride, pad, addend=addend, addend_mask=amask, bn_sums=(z, mask, slab))
     assert torch.equal(dx, dx_ref)
     got = K.bn_backward(dx, mask, z, gamma, vec[0], vec[1], relu=True, slab=slab, presummed=True)
-    assert float(slab[:K._lib.bn_slots()].abs().max()) == 0.0          # self-cleaning: ready for the next step
+    assert float(slab[:2 * K._lib.bn_slots()].abs().max()) == 0.0      # self-cleaning: ready for the next step
     scale = max(1.0, float(ref[2].abs().max()), float(ref[3].abs().max()))
     _close(got[2], ref[2], rtol=2e-3, atol=2e-3 * scale, what="dgamma from epilogue sums")
     _close(got[3], ref[3], rtol=2e-3, atol=2e-3 * scale, what="dbeta from epilogue sums")

@@ -1,0 +1,282 @@
+"""Round-2 GPU checks: the kernel variants the headline benchmark actually runs (BK=32 ring tiles, >256-tile grids,
+million-row filter gradients, the >4 GiB register-staged fallback), BatchNorm statistics under |mean| >> std, the
+captured training step followed by an eager one, the default (native RCCL) reducer transport."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_kernels import CL, _close, _dev, _rand_act
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# tiles = ceil(N*P*Q / 256) * ceil(K / 128) > 256 selects the BK=32 ring kernel (two resident blocks per CU): the variant
+# that carries 15 of the 38.8 ms of the ResNet-50 step (profiles/r1_resnet50_b512_step_overlapped_kernel_summary_final.txt)
+BENCH_SCALE_CASES = [
+    # N, C, H, W, K, R, stride, pad
+    (32, 64, 56, 56, 256, 1, 1, 0),      # layer1 conv3: 392 x 2 tiles, <128,32>
+    (32, 256, 56, 56, 64, 1, 1, 0),      # layer1 conv1 of later blocks: 392 tiles, <64,32>
+    (128, 128, 28, 28, 128, 3, 1, 1),    # layer2 conv2: 392 tiles, 36 K-steps of 32
+    (16, 16, 115, 115, 64, 4, 1, 0),     # the space-to-depth stem at N=16: 784 tiles, <64,32>
+    (128, 256, 56, 56, 128, 1, 2, 0),    # strided 1x1 (dgrad through parity classes): 392 tiles
+]
+
+
+@pytest.mark.parametrize("case", BENCH_SCALE_CASES)
+def test_conv_kernels_at_benchmark_grid_sizes(case):
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    N, C, H, W, Kc, R, stride, pad = case
+    x = _rand_act((N, C, H, W), 1)
+    w = (torch.randn((Kc, C, R, R), generator=torch.Generator().manual_seed(2)) / (C * R * R) ** 0.5)
+    w = w.to(_dev()).contiguous(memory_format=CL)
+    w_krsc, w_crsk = K.filter_repack(w)
+    wq = w_krsc.permute(0, 3, 1, 2).float()
+    P, Q = K.conv_out_size(H, R, stride, pad), K.conv_out_size(W, R, stride, pad)
+    assert -(-N * P * Q // 256) * -(-Kc // 128) > 256, "case must select the BK=32 ring kernel"
+
+    y, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True)
+    y_ref = F.conv2d(x.float(), wq, None, stride, pad)
+    _close(y, y_ref, what="conv fwd (BK=32)")
+    s = K.slab_sums(stats)
+    yf = y.float()
+    _close(s[0], yf.sum((0, 2, 3)), rtol=2e-3, atol=1e-1 * max(1.0, yf.abs().max().item()), what="fused sum")
+    _close(s[1], (yf * yf).sum((0, 2, 3)), rtol=2e-3, atol=1e-1, what="fused sumsq")
+    dy = _rand_act(tuple(y.shape), 3)
+    dx = K.conv2d_dgrad(dy, w_crsk, (H, W), stride, pad)
+    dx_ref = torch.nn.grad.conv2d_input((N, C, H, W), wq, dy.float(), stride, pad)
+    _close(dx, dx_ref, what="conv dgrad (BK=32)")
+    dw = K.conv2d_wgrad(dy, x, R, R, stride, pad)
+    dw_ref = torch.nn.grad.conv2d_weight(x.float(), (Kc, C, R, R), dy.float(), stride, pad)
+    _close(dw, dw_ref, rtol=1e-2, atol=1e-2 * dw_ref.abs().max().item(), what="conv wgrad")
+
+
+@pytest.mark.parametrize("env", [{"DDL_RING_BK": "32"}, {"DDL_RING_BK": "64"}, {"DDL_CONV_RING": "0"}],
+                         ids=["ring-bk32", "ring-bk64", "register-staged"])
+def test_every_conv_case_under_each_forced_kernel_variant(env):
+    """The selection knobs are read once per process, so each variant gets a child process that runs ALL of CONV_CASES:
+    BK=32 (and its 3*((row>>3)&1) swizzle) on small grids, BK=64 on every grid, and the register-staged conv_igemm
+    kernel that large (> 4 GiB) operands fall back to."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_conv_cases_child.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "0 failed" in r.stdout
+
+
+def test_wgrad_over_a_million_rows_matches_fp32():
+    """Split-M filter gradient with M = N*P*Q = 1.2 M rows (ResNet-50 layer1 at batch 384): fp32 atomics over thousands of
+    partial tiles must still agree with an fp32 GEMM."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W, Kc = 384, 64, 56, 56, 64
+    x = _rand_act((N, C, H, W), 5)
+    dy = _rand_act((N, Kc, H, W), 6)
+    dw = K.conv2d_wgrad(dy, x, 1, 1, 1, 0)
+    xm = x.permute(0, 2, 3, 1).reshape(-1, C).float()
+    dym = dy.permute(0, 2, 3, 1).reshape(-1, Kc).float()
+    assert xm.shape[0] > 1_000_000
+    ref = (dym.double().t() @ xm.double()).float().view(Kc, C, 1, 1)
+    _close(dw, ref, rtol=2e-3, atol=2e-3 * ref.abs().max().item(), what="wgrad, 1.2M rows")
+    # 3x3 at the same scale, accumulated INTO an existing gradient (the arena path)
+    w3 = torch.full((Kc, C, 3, 3), 0.5, device=_dev()).contiguous(memory_format=CL)
+    out = K.conv2d_wgrad(dy, x, 3, 3, 1, 1, out=w3)
+    ref3 = torch.nn.grad.conv2d_weight(x[:64].float(), (Kc, C, 3, 3), dy[:64].float(), 1, 1)
+    for i in range(64, N, 64):
+        ref3 += torch.nn.grad.conv2d_weight(x[i:i + 64].float(), (Kc, C, 3, 3), dy[i:i + 64].float(), 1, 1)
+    _close(out, ref3 + 0.5, rtol=5e-3, atol=5e-3 * ref3.abs().max().item(), what="wgrad 3x3 accumulate, 1.2M rows")
+
+
+def test_conv_with_an_operand_beyond_4_gib_takes_the_register_staged_kernel():
+    """in_bytes >= 0xFFFF0000: 32-bit buffer offsets of the LDS-DMA ring kernel do not reach, the launcher must fall back
+    to conv_igemm (64-bit addressing) and the result must still be right at the far end of the tensor."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W, Kc = 66, 64, 720, 720, 8
+    assert N * C * H * W * 2 >= 0xFFFF0000
+    g = torch.Generator(device=_dev()).manual_seed(3)
+    x = torch.randn((N, H, W, C), generator=g, device=_dev(), dtype=torch.bfloat16).permute(0, 3, 1, 2)
+    w = (torch.randn((Kc, C, 1, 1), generator=torch.Generator().manual_seed(2)) / C ** 0.5).to(_dev()).contiguous(memory_format=CL)
+    w_krsc, w_crsk = K.filter_repack(w)
+    y, _ = K.conv2d_fwd(x, w_krsc, 1, 0)
+    wm = w_krsc.reshape(Kc, C).float()
+    for n in (0, N // 2, N - 1):                         # first, middle and LAST image (past the 4 GiB mark)
+        ref = (x[n].permute(1, 2, 0).reshape(-1, C).float() @ wm.t()).view(H, W, Kc).permute(2, 0, 1)
+        _close(y[n], ref, what=f"conv fwd, image {n} of a 4.4 GB input")
+    del y
+    dy = torch.randn((N, H, W, Kc), generator=g, device=_dev(), dtype=torch.bfloat16).permute(0, 3, 1, 2)
+    dx = K.conv2d_dgrad(dy, w_crsk, (H, W), 1, 0)          # OUTPUT beyond 4 GiB
+    for n in (0, N - 1):
+        ref = (dy[n].permute(1, 2, 0).reshape(-1, Kc).float() @ wm).view(H, W, C).permute(2, 0, 1)
+        _close(dx[n], ref, what=f"conv dgrad, image {n}")
+
+
+@pytest.mark.parametrize("mean,std", [(50.0, 0.1), (-300.0, 2.0), (0.5, 2.0)])
+@pytest.mark.parametrize("fused", [False, True], ids=["bn_stats", "conv_epilogue"])
+def test_bn_statistics_survive_a_mean_far_from_zero(mean, std, fused):
+    """var = E[x^2] - E[x]^2 in fp32 cancels when |mean| >> std.  Reference: F.batch_norm on the same bf16-rounded data in
+    fp32 (two-pass).  `fused`: statistics from the conv epilogue (identity 1x1 filter) instead of the stand-alone pass."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W = 64, 64, 28, 28
+    g = torch.Generator().manual_seed(7)
+    x = (torch.randn((N, C, H, W), generator=g) * std + mean).to(torch.bfloat16).to(_dev()).contiguous(memory_format=CL)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(_dev())
+    beta = (torch.randn(C, generator=g) * 0.1).to(_dev())
+    rm, rv = torch.zeros(C, device=_dev()), torch.ones(C, device=_dev())
+    if fused:
+        eye = torch.eye(C, device=_dev()).view(C, C, 1, 1).contiguous(memory_format=CL)
+        wk, _ = K.filter_repack(eye)
+        y, slab = K.conv2d_fwd(x, wk, 1, 0, want_stats=True)
+        assert torch.equal(y, x)
+    else:
+        slab = K.bn_stats(x)
+    vec = K.bn_finalize(slab, N * H * W, gamma, beta, rm, rv, 0.1, 1e-5)
+    xf = x.float()
+    mu_ref = xf.mean((0, 2, 3))
+    var_ref = xf.var((0, 2, 3), unbiased=False)
+    _close(vec[0], mu_ref, rtol=1e-5, atol=1e-5 * abs(mean) + 1e-6, what="batch mean")
+    _close(vec[1], torch.rsqrt(var_ref + 1e-5), rtol=5e-3, atol=0.0, what="batch invstd")
+    out = K.bn_apply(x, vec[2], vec[3], relu=False)
+    ref = F.batch_norm(xf, None, None, gamma, beta, True, 0.1, 1e-5)
+    _close(out, ref, rtol=2e-2, atol=3e-2, what="normalised output")
+
+
+def test_eager_step_right_after_graph_capture_uses_live_weights():
+    """GraphedTrainStep must invalidate the derived-weight caches it filled during capture (they live in the graph's
+    private pool and were never executed): an eager evaluation right after the capture has to match a model that never
+    captured anything (ragged batch after capture trained on uninitialised packs)."""
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import ParamArena
+    from distributed_deep_learning_amd.utils import GraphedTrainStep
+
+    def build():
+        torch.manual_seed(11)
+        m = models.build("lenet5").to(_dev())       # conv1 / conv2 use pad_out packs that are NOT arena-backed
+        arena = ParamArena(m.named_parameters())
+        return m, FusedSGD(arena, lr=0.05, momentum=0.9), SoftmaxCrossEntropyLoss()
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn((32, 1, 28, 28), generator=g).to(_dev())
+    y = torch.randint(0, 10, (32,), generator=g).to(_dev())
+    xr = torch.randn((9, 1, 28, 28), generator=g).to(_dev())        # a ragged batch: runs eagerly
+    yr = torch.randint(0, 10, (9,), generator=g).to(_dev())
+
+    m1, o1, c1 = build()
+    step = GraphedTrainStep(m1, c1, o1, x, y, warmup=1)             # one eager warm-up step, then the capture
+    loss_eager_after_capture = c1(m1(xr), yr).item()                # eager forward BEFORE any replay
+    m2, o2, c2 = build()
+    c2(m2(x), y).backward()
+    o2.step()                                                       # the same single (warm-up) step, never captured
+    loss_ref = c2(m2(xr), yr).item()
+    assert abs(loss_eager_after_capture - loss_ref) < 2e-2 * max(1.0, abs(loss_ref)), (loss_eager_after_capture, loss_ref)
+    # and replays keep training the same model
+    l0 = step(x, y).item()
+    for _ in range(10):
+        l1 = step(x, y).item()
+    assert l1 < l0
+
+
+def test_default_reducer_transport_is_the_native_communicator():
+    """World 1 with the collectives forced: comm=None picks the native RCCL communicator on the GPU, its start-up check
+    against torch.distributed passes, ncclCommCount reports the world, barrier() returns."""
+    import torch.distributed as td
+    from distributed_deep_learning_amd import dist as ddist
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    ddist.init(ddist.RankInfo(0, 1, 0, 1), _dev(), force=True)
+    try:
+        m = models.build("resnet18_cifar").to(_dev())
+        d = DistributedDataParallel(m, bucket_mb=8, force_collectives=True)
+        assert d.ncomm is not None and d.comm_note is None
+        assert d.comm_ranks() == 1 and d.ncomm.user_rank() == 0
+        d.ncomm.barrier()
+        d.close()
+    finally:
+        td.destroy_process_group()
+
+
+# --------------------------------------------------------------------------------------------- Linear on our GEMM
+@pytest.mark.parametrize("B,fin,fout,relu,bias", [(128, 2048, 1000, False, True), (32, 25088, 4096, True, True),
+                                                  (100, 400, 120, True, True), (9, 84, 10, False, True),
+                                                  (64, 128, 6, False, False), (256, 4096, 4096, True, True)])
+def test_linear_fwd_bwd_matches_fp32(B, fin, fout, relu, bias):
+    """forward, input gradient, weight gradient and bias gradient of nn.Linear (all on ops.kernels.gemm_tn) against fp32
+    F.linear on the bf16-rounded operands; covers VGG-16's 25088x4096, ragged batches and feature counts that are not
+    multiples of 8."""
+    from distributed_deep_learning_amd import nn as dnn
+    g = torch.Generator().manual_seed(5)
+    lin = dnn.Linear(fin, fout, bias=bias).to(_dev())
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn((fout, fin), generator=g) / fin ** 0.5)
+        if bias:
+            lin.bias.copy_(torch.randn(fout, generator=g) * 0.1)
+    x = torch.randn((B, fin), generator=g).to(torch.bfloat16).to(_dev()).requires_grad_(True)
+    y = lin(x, relu=relu)
+    assert y.shape == (B, fout) and y.dtype == torch.bfloat16
+    wq = lin.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    bq = lin.bias.detach().clone().requires_grad_(True) if bias else None
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.linear(xr, wq, bq)
+    if relu:
+        ref = F.relu(ref)
+    _close(y, ref, what="linear fwd")
+    dy = torch.randn((B, fout), generator=g).to(torch.bfloat16).to(_dev())
+    y.backward(dy)
+    # same gate as the kernel's own (bf16-rounded) output so rounding at 0 cannot flip elements between the two
+    gate = (y.detach().float() > 0).float() if relu else torch.ones_like(ref)
+    F.linear(xr, wq, bq).backward(dy.float() * gate)
+    _close(x.grad, xr.grad, what="linear dx")
+    _close(lin.weight.grad, wq.grad, rtol=1e-2, atol=1e-2 * wq.grad.abs().max().item(), what="linear dW")
+    if bias:
+        _close(lin.bias.grad, bq.grad, rtol=1e-2, atol=1e-2 * max(1.0, bq.grad.abs().max().item()), what="linear db")
+
+
+def test_linear_gradients_go_straight_into_the_arena_and_dropout_gates_backward():
+    from distributed_deep_learning_amd import nn as dnn
+    from distributed_deep_learning_amd.parallel import ParamArena
+    torch.manual_seed(3)
+    lin = dnn.Linear(512, 256).to(_dev())
+    arena = ParamArena(lin.named_parameters())
+    assert lin.weight._ddl_shadow_t.shape == (512, 256)                        # the arena keeps the [in, out] twin
+    assert torch.equal(lin.weight._ddl_shadow_t, lin.weight.detach().to(torch.bfloat16).t())
+    x = torch.randn((64, 512), device=_dev()).to(torch.bfloat16).requires_grad_(True)
+    lin.train()
+    y = lin(x, relu=True, dropout=0.5)
+    kept = (y.detach().float() > 0).float().mean().item()
+    assert 0.15 < kept < 0.35, kept                                             # ~ half of the ~half that ReLU leaves
+    y2 = lin(x, relu=True, dropout=0.5)
+    assert not torch.equal(y, y2)                                               # the device-side counter advanced
+    ref = F.relu(F.linear(x.detach().float(), lin.weight.detach().to(torch.bfloat16).float(), lin.bias.detach()))
+    live = y.detach().float() > 0
+    _close(y.detach().float()[live], 2.0 * ref[live], what="kept elements are scaled by 1/(1-p)")
+    arena.zero_grad()
+    y.backward(torch.ones_like(y))
+    from distributed_deep_learning_amd.ops import streams
+    streams.join()
+    gq = live.float() * 2.0
+    _close(lin.bias.grad, gq.sum(0), rtol=1e-2, atol=1e-1, what="db through the dropout gate")
+    _close(lin.weight.grad, gq.t() @ x.detach().float(), rtol=1e-2, atol=2e-1, what="dW through the dropout gate")
+    assert arena.grad_is_arena_view(lin.weight) and arena.grad_is_arena_view(lin.bias)
+    lin.eval()
+    _close(lin(x, relu=True, dropout=0.5), ref, what="eval mode: no dropout")
+
+
+def test_l1_loss_kernel_matches_torch():
+    from distributed_deep_learning_amd import nn as dnn
+    g = torch.Generator().manual_seed(9)
+    for dtype in (torch.float32, torch.bfloat16):
+        p = torch.randn((300, 5), generator=g).to(dtype).to(_dev()).requires_grad_(True)
+        t = torch.randn((300, 5), generator=g).to(_dev())
+        loss = dnn.L1Loss()(p, t)
+        pr = p.detach().float().requires_grad_(True)
+        ref = F.l1_loss(pr, t)
+        assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+        loss.backward()
+        ref.backward()
+        _close(p.grad, pr.grad, rtol=1e-2, atol=1e-6, what="l1 grad")
