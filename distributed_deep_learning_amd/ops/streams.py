@@ -34,6 +34,8 @@ _dirty: set[int] = set()
 _callback_queued = False
 _LIFETIME = os.environ.get("DDL_SIDE_LIFETIME", "hold")      # hold | join | record_stream (the old policy), for A/B runs
 _RECORD_STREAM = _LIFETIME == "record_stream"
+_KEEP_JOINS = int(os.environ.get("DDL_SIDE_KEEP_JOINS", "0"))     # experiment: release operands only k joins later
+_grave: list = []
 _held: dict[int, list] = {}          # device -> [(event or None, operands)] still (possibly) read on the side stream
 
 
@@ -63,25 +65,32 @@ def _overlaps(main: torch.cuda.Stream, cand: torch.cuda.Stream, us: int = 150) -
     return a.elapsed_time(b) * 1e3 < 1.6 * us
 
 
+def _lib_error():
+    from . import _lib
+    return (_lib.HipKernelError, RuntimeError)
+
+
 def _stream(index: int) -> torch.cuda.Stream:
     s = _side.get(index)
     if s is None:
         # HIP deals streams round-robin onto GPU_MAX_HW_QUEUES (4) hardware queues; once other libraries (RCCL, MIOpen)
         # have created theirs, a new stream can land on the MAIN stream's queue, where it overlaps nothing (seen in
         # rocprof: same queue id, kernel-time sum == busy time, -2 ms per step).  So the candidates are MEASURED and the
-        # first one that really runs beside the current stream is kept.  All at normal priority: a high-priority side
-        # stream gets a queue of its own by construction, but deadlocked (GPU-side, cross-queue barrier never
-        # released) in a process that had run MIOpen's RNN before — DDL_WGRAD_STREAM_PRIORITY=-1 re-enables that.
-        prio = int(os.environ.get("DDL_WGRAD_STREAM_PRIORITY", "0"))
+        # first one that really runs beside the current stream is kept.
+        # Always NORMAL priority.  A high-priority stream gets a hardware queue of its own by construction, but a
+        # fork/join between a high-priority and a normal-priority stream deadlocks on the GPU as soon as the process
+        # holds more streams than hardware queues (bench/probes/prio_stream_probe.py: {normal, high} x {0, 8 extra
+        # streams} - only high+8 hangs, within the first 500 iterations; MIOpen's RNN and gloo's GPU collectives put a
+        # process into that regime, which is how round 1 met it).  There is no switch to turn that back on.
         main = torch.cuda.current_stream(index)
         cands = []
-        for _ in range(1 if prio != 0 else 5):
-            c = torch.cuda.Stream(device=index, priority=prio)
+        for _ in range(5):
+            c = torch.cuda.Stream(device=index, priority=0)
             cands.append(c)
             try:
-                if prio != 0 or torch.cuda.is_current_stream_capturing() or _overlaps(main, c):
+                if torch.cuda.is_current_stream_capturing() or _overlaps(main, c):
                     break
-            except Exception:                       # noqa: BLE001 - calibration is best effort
+            except _lib_error():                    # the calibration kernel could not be launched: keep the candidate
                 break
         s = cands[-1]
         _side[index] = s
@@ -141,7 +150,11 @@ def join() -> None:
         torch.cuda.current_stream(index).wait_stream(_side[index])
         # everything enqueued on the current stream from here on is ordered behind the side stream: the operands'
         # memory may be reused by it
-        _held.pop(index, None)
+        gone = _held.pop(index, None)
+        if _KEEP_JOINS > 0 and gone:
+            _grave.append(gone)
+            while len(_grave) > _KEEP_JOINS:
+                _grave.pop(0)
     _dirty.clear()
 
 

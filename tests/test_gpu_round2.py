@@ -280,3 +280,28 @@ def test_l1_loss_kernel_matches_torch():
         loss.backward()
         ref.backward()
         _close(p.grad, pr.grad, rtol=1e-2, atol=1e-6, what="l1 grad")
+
+
+def test_side_stream_fork_join_survives_more_streams_than_hardware_queues():
+    """The side stream is always normal priority (a high-priority one deadlocks a fork/join once the process holds more
+    streams than hardware queues: bench/probes/prio_stream_probe.py, docs/STATUS.md) and the old switch is gone."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    from distributed_deep_learning_amd.ops import streams
+    os.environ["DDL_WGRAD_STREAM_PRIORITY"] = "-1"                  # must be ignored
+    try:
+        extra = [torch.cuda.Stream(device=_dev()) for _ in range(8)]
+        x = _rand_act((4, 64, 16, 16), 1)
+        for i in range(600):
+            y = K.relu_fwd(x)
+            with streams.fork(y):
+                z = K.relu_fwd(y)
+            with torch.cuda.stream(extra[i % 8]):
+                K.relu_fwd(x)
+            if i % 50 == 49:
+                streams.join()
+        streams.join()
+        torch.cuda.synchronize()
+        assert streams._stream(0).priority == 0                     # noqa: SLF001
+        assert torch.equal(z.float(), F.relu(x.float()))
+    finally:
+        os.environ.pop("DDL_WGRAD_STREAM_PRIORITY", None)
