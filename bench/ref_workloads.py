@@ -4,7 +4,9 @@
 
     ours, eager     this framework's kernels, step launched from Python
     ours, hipGraph  the same step replayed from one captured graph (utils.GraphedTrainStep)
-    stock           the same architecture from plain torch.nn modules in fp32 (what the reference runs), eager
+    stock fp32      the same architecture from plain torch.nn modules in fp32 (what the reference runs), eager
+    stock bf16      the same under torch.autocast(bfloat16) (+ channels_last for the CNN): the SAME-PRECISION comparator
+                    for our bf16 CNN / LSTM paths (our MLP path is fp32, so its comparator is the fp32 column)
 
     python bench/ref_workloads.py [--batches 32,512] [--steps 100]
 """
@@ -105,7 +107,8 @@ def workload(name, B):
     if name == "lstm":
         x = torch.randn(B, 10, 32, generator=g).to(dev)
         y = torch.randn(B, 5, generator=g).to(dev)
-        return x, y, tnn.L1Loss, tnn.L1Loss, "adam", StockLSTM
+        from distributed_deep_learning_amd.nn import L1Loss
+        return x, y, L1Loss, tnn.L1Loss, "adam", StockLSTM
     x = torch.randn(B, 48, generator=g).to(dev)
     y = torch.randint(0, 5, (B,), generator=g).to(dev)
     return x, y, SoftmaxCrossEntropyLoss, tnn.CrossEntropyLoss, "sgd", stock_mlp
@@ -128,16 +131,20 @@ def ours(name, x, y, crit_cls, opt_kind, steps, graph):
     return timeit(step, steps)
 
 
-def stock(x, y, crit_cls, opt_kind, factory, steps):
+def stock(x, y, crit_cls, opt_kind, factory, steps, amp=False):
     torch.manual_seed(0)
     m = factory().to(dev)
+    if amp and x.dim() == 4:
+        m = m.to(memory_format=torch.channels_last)
+        x = x.contiguous(memory_format=torch.channels_last)
     opt = torch.optim.Adam(m.parameters(), lr=1e-3) if opt_kind == "adam" else \
         torch.optim.SGD(m.parameters(), lr=0.01, momentum=0.9)
     crit = crit_cls()
 
     def step():
         opt.zero_grad(set_to_none=True)
-        loss = crit(m(x), y)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            loss = crit(m(x).float(), y)
         loss.backward()
         opt.step()
     return timeit(step, steps)
@@ -149,8 +156,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--workloads", default="cnn,lstm,mlp")
     a = ap.parse_args()
-    print(f"{'workload':>8} {'batch':>6} | {'ours eager':>18} | {'ours hipGraph':>18} | {'stock fp32 eager':>18} | best/stock",
-          flush=True)
+    print(f"{'workload':>8} {'batch':>6} | {'ours eager':>18} | {'ours hipGraph':>18} | {'stock fp32 eager':>18} | "
+          f"{'stock bf16 autocast':>19} | vs fp32 | vs bf16", flush=True)
     for name in a.workloads.split(","):
         for B in map(int, a.batches.split(",")):
             x, y, crit_o, crit_s, opt_kind, factory = workload(name, B)
@@ -161,11 +168,16 @@ def main():
                 print(f"   graph capture failed for {name}: {type(e).__name__}: {e}", flush=True)
                 tg = float("nan")
             ts = stock(x, y, crit_s, opt_kind, factory, a.steps)
+            try:
+                tb = stock(x, y, crit_s, opt_kind, factory, a.steps, amp=True)
+            except Exception as e:                     # noqa: BLE001 - e.g. MIOpen without a bf16 RNN path
+                print(f"   stock bf16 autocast failed for {name}: {type(e).__name__}: {e}", flush=True)
+                tb = float("nan")
             best = min(t for t in (te, tg) if t == t)
 
             def f(t):
                 return f"{t:7.3f} ms {B / t * 1e3:8.0f}/s"
-            print(f"{name:>8} {B:>6} | {f(te)} | {f(tg)} | {f(ts)} | {ts / best:5.2f}x", flush=True)
+            print(f"{name:>8} {B:>6} | {f(te)} | {f(tg)} | {f(ts)} | {f(tb)}  | {ts / best:5.2f}x  | {tb / best:5.2f}x", flush=True)
 
 
 if __name__ == "__main__":

@@ -118,12 +118,32 @@ __device__ __forceinline__ void slab_fold(float* __restrict__ slab_f, int nslots
   const int c = blockIdx.x * 64 + cc;
   double a = 0.0, b = 0.0;
   if (c < C) {
-#pragma unroll 4
-    for (int s = w; s < nslots; s += 4) {
-      double* p0 = slab + ((size_t)s * 2 + 0) * C + c;
-      double* p1 = slab + ((size_t)s * 2 + 1) * C + c;
-      a += *p0; b += *p1;
-      *p0 = 0.0; *p1 = 0.0;
+    // ALL loads of a thread are issued before the first is consumed: these kernels sit on the critical path between two
+    // bandwidth-bound passes while the side stream saturates HBM, where a dependent read costs 2-3 us - four
+    // serialised batches of loads made this 13-19 us per call (rocprof), one batch makes it one round trip.
+    constexpr int PER = BN_SLOTS / 4;
+    double va[PER], vb[PER];
+    if (nslots == BN_SLOTS) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const size_t s = (size_t)(w + 4 * i);
+        va[i] = __builtin_nontemporal_load(slab + (s * 2 + 0) * C + c);
+        vb[i] = __builtin_nontemporal_load(slab + (s * 2 + 1) * C + c);
+      }
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const size_t s = (size_t)(w + 4 * i);
+        a += va[i]; b += vb[i];
+        slab[(s * 2 + 0) * C + c] = 0.0;
+        slab[(s * 2 + 1) * C + c] = 0.0;
+      }
+    } else {
+      for (int s = w; s < nslots; s += 4) {
+        double* p0 = slab + ((size_t)s * 2 + 0) * C + c;
+        double* p1 = slab + ((size_t)s * 2 + 1) * C + c;
+        a += *p0; b += *p1;
+        *p0 = 0.0; *p1 = 0.0;
+      }
     }
   }
   part[w][0][cc] = a;

@@ -250,3 +250,109 @@ extern "C" int ddl_l1_loss(const void* pred, int pred_is_bf16, const float* targ
                        grad, out, n);
   return (int)hipGetLastError();
 }
+
+// ================================================================ kernel-size-1 Conv1d + ReLU (the LSTM workload's front)
+// y[b][o][l] = relu(bias[o] + sum_c w[o][c] * x[b][c][l]):  /root/reference/src/pytorch/LSTM/model.py:70-71 applies
+// Conv1d(history=10 -> 64, k=1) + ReLU to a [B, 10, 32] window, and the LSTM then walks the 64 output channels as
+// time steps.  The reduction is 10 deep: far too short for MFMA (K = 32 per instruction), so this is a VALU kernel;
+// its output is written as bf16 in exactly the [B][T=64][I=32] layout the fused LSTM kernel reads.
+// One thread = one (b, o) row x 8 consecutive l.
+__global__ __launch_bounds__(256) void conv1d_k1_relu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                 const float* __restrict__ bias, bf16_t* __restrict__ y,
+                                                                 int B, int C, int O, int L8, long long total) {
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int lc = (int)(t % L8);
+    const long long r = t / L8;
+    const int o = (int)(r % O);
+    const long long b = r / O;
+    const float bo = bias != nullptr ? bias[o] : 0.f;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = bo;
+    const float* xb = x + (b * C) * (long long)(L8 * 8) + lc * 8;
+    for (int c = 0; c < C; ++c) {
+      const float wv = w[o * C + c];
+      const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (long long)c * L8 * 8);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long long)c * L8 * 8 + 4);
+      acc[0] += wv * a[0]; acc[1] += wv * a[1]; acc[2] += wv * a[2]; acc[3] += wv * a[3];
+      acc[4] += wv * d[0]; acc[5] += wv * d[1]; acc[6] += wv * d[2]; acc[7] += wv * d[3];
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    *reinterpret_cast<u32x4*>(y + t * 8) = pack8(acc);
+  }
+}
+
+// dw[o][c] += sum_{b,l} g x[b][c][l],  db[o] += sum_{b,l} g,  g = dy * [y > 0].   Block = (O rows) x (L8 chunks) threads
+// (<= 1024), grid-strided over b; per-thread partial sums for all c (C <= 16) in registers, folded over the l-chunks
+// through LDS, one atomic per (o, c) per block.
+template <int CMAX>
+__global__ __launch_bounds__(1024) void conv1d_k1_relu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
+                                                                  const float* __restrict__ x, float* __restrict__ dw,
+                                                                  float* __restrict__ db, int B, int C, int O, int L8) {
+  extern __shared__ float red[];                       // [O * L8][CMAX + 1]
+  const int tid = threadIdx.x;
+  const int nthr = O * L8;
+  float acc[CMAX + 1];
+#pragma unroll
+  for (int c = 0; c <= CMAX; ++c) acc[c] = 0.f;
+  if (tid < nthr) {
+    const int lc = tid % L8, o = tid / L8;
+    for (long long b = blockIdx.x; b < B; b += gridDim.x) {
+      const long long off = ((b * O + o) * (long long)L8 + lc) * 8;
+      float g[8], yf[8];
+      unpack8(*reinterpret_cast<const u32x4*>(dy + off), g);
+      unpack8(*reinterpret_cast<const u32x4*>(y + off), yf);
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { g[e] = yf[e] > 0.f ? g[e] : 0.f; s += g[e]; }
+      acc[CMAX] += s;
+      const float* xb = x + (b * C) * (long long)(L8 * 8) + lc * 8;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        if (c < C) {
+          const f32x4 a = *reinterpret_cast<const f32x4*>(xb + (long long)c * L8 * 8);
+          const f32x4 d = *reinterpret_cast<const f32x4*>(xb + (long long)c * L8 * 8 + 4);
+          acc[c] += g[0] * a[0] + g[1] * a[1] + g[2] * a[2] + g[3] * a[3] + g[4] * d[0] + g[5] * d[1] + g[6] * d[2] + g[7] * d[3];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c <= CMAX; ++c) red[tid * (CMAX + 1) + c] = acc[c];
+  }
+  __syncthreads();
+  for (int i = tid; i < O * (CMAX + 1); i += blockDim.x) {
+    const int o = i / (CMAX + 1), c = i % (CMAX + 1);
+    if (c < C || c == CMAX) {
+      float s = 0.f;
+      for (int lc = 0; lc < L8; ++lc) s += red[(o * L8 + lc) * (CMAX + 1) + c];
+      if (c == CMAX) { if (db != nullptr) atomicAdd(&db[o], s); }
+      else atomicAdd(&dw[o * C + c], s);
+    }
+  }
+}
+
+extern "C" int ddl_conv1d_k1_relu_fwd(const float* x, const float* w, const float* bias, void* y, int B, int C, int O, int L,
+                                      void* stream) {
+  if (B <= 0 || C <= 0 || O <= 0 || L <= 0 || L % 8 != 0) return -1;
+  const long long total = (long long)B * O * (L / 8);
+  hipLaunchKernelGGL(conv1d_k1_relu_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
+                     (bf16_t*)y, B, C, O, L / 8, total);
+  return (int)hipGetLastError();
+}
+
+// dw [O][C] and db [O] (may be null) are ACCUMULATED into (arena gradients); C <= 16, O * L/8 <= 1024.
+extern "C" int ddl_conv1d_k1_relu_bwd(const void* dy, const void* y, const float* x, float* dw, float* db, int B, int C, int O,
+                                      int L, void* stream) {
+  if (B <= 0 || C <= 0 || C > 16 || O <= 0 || L <= 0 || L % 8 != 0 || O * (L / 8) > 1024) return -1;
+  const int L8 = L / 8, nthr = O * L8;
+  const int block = ((nthr + 63) / 64) * 64;
+  const int smem = nthr * 17 * (int)sizeof(float);
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv1d_k1_relu_bwd_kernel<16>), smem);
+  if (rc != 0) return rc;
+  const int grid = B < 512 ? B : 512;
+  hipLaunchKernelGGL((conv1d_k1_relu_bwd_kernel<16>), dim3(grid), dim3(block), smem, (hipStream_t)stream,
+                     (const bf16_t*)dy, (const bf16_t*)y, x, dw, db, B, C, O, L8);
+  return (int)hipGetLastError();
+}

@@ -10,6 +10,8 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
+from ..nn import functional as _F
+from ..ops import kernels as _K
 
 
 class LSTMRef(tnn.Module):
@@ -23,14 +25,13 @@ class LSTMRef(tnn.Module):
         self.fc = dnn.Linear(hidden_params, classes)
 
     def _front(self, x):
-        # conv+ReLU, MaxPool1d(1)+ReLU == ReLU.  A kernel-size-1 Conv1d is a Linear over the channel axis: computed as
-        # ONE GEMM [B*32, 10] x [10, 64] (MIOpen's Conv1d costs seconds of kernel search / compilation on first use,
-        # which dominated short runs of this workload; a broadcast matmul turns into B tiny GEMMs); the Conv1d module
-        # stays the parameter container (state_dict keys).
+        # conv+ReLU, MaxPool1d(1)+ReLU == ReLU.  GPU: one VALU kernel (the reduction is only `history` = 10 deep) that
+        # writes bf16 in the [B, T=64, I=32] layout the fused LSTM kernel reads, weight / bias gradients straight into the
+        # arena (nn.functional.Conv1dK1Relu); the Conv1d module stays the parameter container (state_dict keys).
         x = x.float()
-        if x.is_cuda and x.shape[0] < 1024:       # big batches amortise MIOpen's start-up and its conv is 0.3 ms faster
-            y = torch.nn.functional.linear(x.transpose(1, 2), self.conv.weight[:, :, 0], self.conv.bias)   # [B, 32, 64]
-            return torch.relu(y).transpose(1, 2)                                                           # [B, 64, 32]
+        if (x.is_cuda and not x.requires_grad and x.is_contiguous()
+                and _K.conv1d_k1_supported(x.shape[1], self.conv.out_channels, x.shape[2])):
+            return _F.Conv1dK1Relu.apply(x, self.conv.weight, self.conv.bias)
         return torch.relu(self.conv(x))
 
     def _lstm(self, i, x):

@@ -674,6 +674,40 @@ class LinearAct(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+class Conv1dK1Relu(torch.autograd.Function):
+    """``relu(Conv1d(kernel_size=1)(x))`` on raw fp32 input ``[B, C, L]`` -> bf16 ``[B, O, L]`` (``csrc/linear.hip``):
+    the front of the reference's LSTM workload (``/root/reference/src/pytorch/LSTM/model.py:70-71``).  ``weight`` is the
+    Conv1d parameter ``[O, C, 1]``; its gradient and the bias gradient are accumulated straight into the arena when
+    the parameters live there.  The input is data: no input gradient."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w2 = weight.detach().reshape(weight.shape[0], weight.shape[1])
+        y = K.conv1d_k1_relu_fwd(x, w2, None if bias is None else bias.detach())
+        ctx.save_for_backward(x, y)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        weight, bias = ctx.params
+        dy = _bf16(dy).contiguous()
+        arena = getattr(weight, "_ddl_arena", None)
+        direct = (arena is not None and arena.grad_is_arena_view(weight) and weight.grad.is_contiguous()
+                  and (bias is None or (getattr(bias, "_ddl_arena", None) is arena and arena.grad_is_arena_view(bias))))
+        if direct:
+            K.conv1d_k1_relu_bwd(dy, y, x, weight.grad, None if bias is None else bias.grad)
+            arena.notify_grad_ready(weight)
+            if bias is not None:
+                arena.notify_grad_ready(bias)
+            return None, None, None
+        dw = torch.zeros(weight.shape, dtype=torch.float32, device=dy.device)
+        db = torch.zeros(bias.shape, dtype=torch.float32, device=dy.device) if bias is not None else None
+        K.conv1d_k1_relu_bwd(dy, y, x, dw, db)
+        return None, dw, db
+
+
 class L1Loss(torch.autograd.Function):
     """Mean absolute error with the gradient produced in the forward launch (``csrc/linear.hip``): the reference's
     LSTM criterion, ``/root/reference/src/pytorch/LSTM/main.py:163``."""

@@ -63,6 +63,8 @@ _SIGS = {
     "ddl_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _ll, _vp],
     "ddl_cast_rows": [_vp, _vp, _i, _i, _ll, _vp],
     "ddl_l1_loss": [_vp, _i, _vp, _vp, _vp, _ll, _vp],
+    "ddl_conv1d_k1_relu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ddl_conv1d_k1_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ddl_comm_load": [C.c_char_p],
     "ddl_comm_version": [],
     "ddl_comm_unique_id": [_vp],

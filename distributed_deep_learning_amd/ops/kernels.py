@@ -677,6 +677,36 @@ def l1_loss(pred: torch.Tensor, target: torch.Tensor, want_grad: bool = True):
     return out, grad
 
 
+def conv1d_k1_supported(C: int, O: int, L: int) -> bool:
+    return 1 <= C <= 16 and L % 8 == 0 and O * (L // 8) <= 1024
+
+
+def conv1d_k1_relu_fwd(x: torch.Tensor, w: torch.Tensor, bias) -> torch.Tensor:
+    """``relu(conv1d(x, w[:, :, None], bias))`` for fp32 ``x [B, C, L]``, ``w [O, C]`` -> bf16 ``[B, O, L]``."""
+    lib = _lib.require()
+    B, Cc, L = x.shape
+    O = w.shape[0]
+    if x.dtype != torch.float32 or not x.is_contiguous() or w.dtype != torch.float32 or not w.is_contiguous() \
+            or w.shape[1] != Cc or not conv1d_k1_supported(Cc, O, L):
+        raise ValueError("conv1d_k1_relu_fwd: need contiguous fp32 x [B,C,L], w [O,C], C <= 16, L % 8 == 0")
+    _lib.check_device(x, "conv1d_k1_relu_fwd")
+    y = torch.empty((B, O, L), dtype=BF16, device=x.device)
+    check(lib.ddl_conv1d_k1_relu_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, Cc, O, L, stream_ptr()), "conv1d_k1_relu_fwd")
+    return y
+
+
+def conv1d_k1_relu_bwd(dy: torch.Tensor, y: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, db) -> None:
+    """Accumulate the weight (``[O, C]`` fp32) and bias gradients of :func:`conv1d_k1_relu_fwd` into ``dw`` / ``db``."""
+    lib = _lib.require()
+    B, O, L = y.shape
+    Cc = x.shape[1]
+    if dy.dtype != BF16 or not dy.is_contiguous() or dy.shape != y.shape or dw.dtype != torch.float32 \
+            or not dw.is_contiguous() or dw.numel() != O * Cc:
+        raise ValueError("conv1d_k1_relu_bwd: dy must be contiguous bf16 like y, dw contiguous fp32 [O, C]")
+    check(lib.ddl_conv1d_k1_relu_bwd(ptr(dy), ptr(y), ptr(x), ptr(dw), ptr(db), B, Cc, O, L, stream_ptr()),
+          "conv1d_k1_relu_bwd")
+
+
 # ----------------------------------------------------------------------------------------------- fused small MLP
 MLP_MAX_WIDTH, MLP_MAX_LAYERS, _MLP_LDS_FLOATS = 64, 8, (160 * 1024) // 4 - 3 * 64 * 33
 

@@ -305,3 +305,24 @@ def test_side_stream_fork_join_survives_more_streams_than_hardware_queues():
         assert torch.equal(z.float(), F.relu(x.float()))
     finally:
         os.environ.pop("DDL_WGRAD_STREAM_PRIORITY", None)
+
+
+@pytest.mark.parametrize("B", [3, 32, 700])
+def test_conv1d_k1_relu_front_matches_torch(B):
+    """The LSTM workload's front (Conv1d(10 -> 64, k=1) + ReLU on a [B, 10, 32] window) on the VALU kernel: forward and
+    parameter gradients against fp32 torch."""
+    from distributed_deep_learning_amd.nn import functional as DF
+    g = torch.Generator().manual_seed(4)
+    conv = torch.nn.Conv1d(10, 64, 1).to(_dev())
+    x = torch.randn((B, 10, 32), generator=g).to(_dev())
+    y = DF.Conv1dK1Relu.apply(x, conv.weight, conv.bias)
+    ref = F.relu(conv(x))
+    assert y.shape == (B, 64, 32) and y.dtype == torch.bfloat16
+    _close(y, ref, what="conv1d k=1 fwd")
+    dy = torch.randn((B, 64, 32), generator=g).to(torch.bfloat16).to(_dev())
+    y.backward(dy)
+    gw, gb = conv.weight.grad.clone(), conv.bias.grad.clone()
+    conv.zero_grad()
+    (conv(x) * (y.detach().float() > 0)).backward(dy.float())       # same gate as the kernel's own bf16 output
+    _close(gw, conv.weight.grad, rtol=1e-2, atol=1e-2 * conv.weight.grad.abs().max().item(), what="conv1d dW")
+    _close(gb, conv.bias.grad, rtol=1e-2, atol=1e-2 * conv.bias.grad.abs().max().item(), what="conv1d db")
