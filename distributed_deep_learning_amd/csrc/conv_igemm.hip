@@ -313,6 +313,10 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   p.mode_hint = MODE;
   p.trace = g_conv_trace;
   const bool bwd_sums = MODE == 1 && p.stats != nullptr;
+  if (p.in_scale != nullptr) {                                 // fused producer-BN input: ring kernel only
+    if (!ddl_conv_ring_supported(p)) return -11;
+    return ddl_launch_conv_ring(p, MODE, st);
+  }
   if (use_ring && !bwd_sums && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
   if (bwd_sums) return -9;                                     // only the ring kernel's epilogue takes these sums
@@ -326,10 +330,10 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   return launch_conv<128, 128, MODE>(p, st);
 }
 
-extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
-                              const void* addend, const void* addend_mask, int addend_step, const void* bnz,
-                              const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
-                              int pad, int relu, void* stream) {
+static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
+                           const void* addend, const void* addend_mask, int addend_step, const void* bnz,
+                           const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
+                           int pad, int relu, void* stream, const float* in_scale, const float* in_shift) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
   const long long M = (long long)N * OH * OW;
@@ -347,6 +351,8 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
   if (mode == 1 && ((stats != nullptr) != (bnz != nullptr) || (bnz_mask != nullptr && bnz == nullptr))) return -10;
   if (bn_flags < 0 || bn_flags > 3 || (bn_flags != 0 && (bnz == nullptr || bnz_mask != nullptr))) return -10;
   p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask; p.bn_flags = bn_flags;
+  if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale != nullptr && mode != 0)) return -11;
+  p.in_scale = in_scale; p.in_shift = in_shift;
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;
@@ -389,4 +395,21 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
       if (rc != 0) return rc;
     }
   return 0;
+}
+
+extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
+                              const void* addend, const void* addend_mask, int addend_step, const void* bnz,
+                              const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R,
+                              int S, int stride, int pad, int relu, void* stream) {
+  return conv_igemm_impl(mode, in, wmat, out, bias, stats, addend, addend_mask, addend_step, bnz, bnz_mask, bn_flags, N, OH,
+                         OW, IH, IW, IC, OC, R, S, stride, pad, relu, stream, nullptr, nullptr);
+}
+
+// Forward 1x1 / stride-1 convolution whose INPUT is a raw conv output: relu(in * in_scale[c] + in_shift[c]) is formed on
+// the fragments inside the kernel (the producer's BatchNorm + ReLU), statistics of the output go to `stats`.
+extern "C" int ddl_conv_fwd_inbn(const void* in, const void* wmat, void* out, float* stats, const float* in_scale,
+                                 const float* in_shift, int N, int H, int W, int IC, int OC, void* stream) {
+  if (in_scale == nullptr || in_shift == nullptr || stats == nullptr || IC > 512) return -11;
+  return conv_igemm_impl(0, in, wmat, out, nullptr, stats, nullptr, nullptr, 1, nullptr, nullptr, 0, N, H, W, H, W, IC, OC, 1,
+                         1, 1, 0, 0, stream, in_scale, in_shift);
 }

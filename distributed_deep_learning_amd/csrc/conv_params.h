@@ -31,6 +31,11 @@ struct ConvParams {
   // bn_flags bit 0: no mask tensor, the gate is (bnz > 0) (dx is the gradient of a ReLU OUTPUT bnz: conv+bias+ReLU
   // chains); bit 1: store the gated gradient (the consumer then needs no ReLU-backward pass; sum(g) = its bias grad)
   int bn_flags;
+  // forward only, 1x1 / stride 1 (EPI bit 8): the INPUT is a raw conv output z and the operand the MFMAs see is
+  // relu(z * in_scale[c] + in_shift[c]) — the producer's BatchNorm(+ReLU) applied on the fragment after the LDS read, so
+  // the normalised activation is never written or re-read (fp32 [IC] each, IC <= 512).
+  const float* in_scale;
+  const float* in_shift;
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 

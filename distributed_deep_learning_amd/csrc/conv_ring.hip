@@ -34,7 +34,8 @@ __device__ __forceinline__ void lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, cha
 // (The non-temporal hint, aux bit 1, was tried for activation tiles that only one channel tile reads: 25-40 % SLOWER
 // on the 1x1 layers at 56x56 — the tile's lines come from the Infinity Cache, where the producer just left them.)
 
-// EPI bits: 1 = bias / ReLU epilogue, 2 = BN partial sums, 4 = addend (compile-time, so unused paths cost nothing)
+// EPI bits: 1 = bias / ReLU epilogue, 2 = BN partial sums, 4 = addend, 8 = BN(+ReLU) of the producer applied to the
+// input fragments (compile-time, so unused paths cost nothing)
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -161,6 +162,18 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // EPI & 8: per-input-channel scale / shift of the producer's BatchNorm, staged behind the ring ([2][IC] floats;
+  // channels past IC read as scale 0 / shift 0, i.e. relu(0) = 0, matching the zero-filled weight columns)
+  float* const aff = reinterpret_cast<float*>(smem + RNS * STAGE);
+  const int icp = (p.IC + BK - 1) / BK * BK;
+  if constexpr ((EPI & 8) != 0) {
+    for (int c = tid; c < icp; c += 512) {
+      aff[c] = c < p.IC ? p.in_scale[c] : 0.f;
+      aff[icp + c] = c < p.IC ? p.in_shift[c] : 0.f;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the raw s_barrier of the K loop does not wait for LDS stores
+  }
+
   const int ksteps = (p.Kred + BK - 1) / BK;
 
   issue(0);
@@ -202,6 +215,23 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
       // refill the stage tile t-1 just vacated — AFTER this step's fragment reads are in flight, so the address
       // arithmetic of the refill overlaps the LDS latency instead of delaying the first MFMA behind the barrier
       if (ks == 0 && t + 2 < ksteps) issue(stage == 0 ? 2 : stage - 1);
+      if constexpr ((EPI & 8) != 0) {
+        // 1x1 conv: reduction index == input channel.  This lane's 8 fragment elements are channels cb .. cb+7.
+        const int cb = t * BK + ch * 8;
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + cb), s1 = *reinterpret_cast<const f32x4*>(aff + cb + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + icp + cb), h1 = *reinterpret_cast<const f32x4*>(aff + icp + cb + 4);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+          const u32x4 raw = __builtin_bit_cast(u32x4, b[j]);
+          float f[8];
+          unpack8(raw, f);
+          f[0] = fmaxf(f[0] * s0[0] + h0[0], 0.f); f[1] = fmaxf(f[1] * s0[1] + h0[1], 0.f);
+          f[2] = fmaxf(f[2] * s0[2] + h0[2], 0.f); f[3] = fmaxf(f[3] * s0[3] + h0[3], 0.f);
+          f[4] = fmaxf(f[4] * s1[0] + h1[0], 0.f); f[5] = fmaxf(f[5] * s1[1] + h1[1], 0.f);
+          f[6] = fmaxf(f[6] * s1[2] + h1[2], 0.f); f[7] = fmaxf(f[7] * s1[3] + h1[3], 0.f);
+          b[j] = __builtin_bit_cast(bf16x8, pack8(f));
+        }
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -222,7 +252,8 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
 
 template <int BN, int BK, int MODE, int EPI>
 int launch_ring(ConvParams& p, hipStream_t stream) {
-  constexpr int smem = RNS * (RBM + BN) * BK * 2;
+  // EPI & 8: room for the [2][IC <= 512, padded to BK] fp32 affine vectors behind the ring (still two blocks per CU at BK=32)
+  constexpr int smem = RNS * (RBM + BN) * BK * 2 + ((EPI & 8) ? 2 * 512 * 4 : 0);
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, BK, MODE, EPI>), smem);
   if (rc != 0) return rc;
@@ -236,6 +267,10 @@ int launch_ring(ConvParams& p, hipStream_t stream) {
 template <int BN, int BK>
 int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
   if (mode == 0) {
+    if (p.in_scale != nullptr) {                                 // producer BN(+ReLU) applied to the input fragments
+      if (p.stats == nullptr || p.bias != nullptr || p.relu) return -11;
+      return launch_ring<BN, BK, 0, 10>(p, stream);
+    }
     if (p.stats != nullptr) {
       if (p.bias != nullptr || p.relu) return -6;               // statistics are taken of the raw conv output
       return launch_ring<BN, BK, 0, 2>(p, stream);
@@ -263,6 +298,8 @@ int ring_bk(const ConvParams& p) {
 
 // 32-bit byte offsets inside both operands, and room for the out-of-range sentinel above them.
 bool ddl_conv_ring_supported(const ConvParams& p) {
+  if (p.in_scale != nullptr && !(p.mode_hint == 0 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.IC <= 512))
+    return false;
   if (p.mode_hint == 1 && (p.bias != nullptr || p.relu || (p.stats != nullptr && p.bnz == nullptr))) return false;
   if (p.mode_hint == 0 && p.addend != nullptr) return false;
   if (p.stats != nullptr && (p.bias != nullptr || p.relu)) return false;

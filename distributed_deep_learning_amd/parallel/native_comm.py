@@ -29,7 +29,7 @@ from typing import Optional
 import torch
 
 from ..ops import _lib
-from ..ops._lib import check
+from ..ops._lib import check, device_of
 
 _DT = {torch.float32: 0, torch.bfloat16: 1}
 
@@ -42,13 +42,14 @@ def _rccl_path() -> Optional[bytes]:
 class _Handle:
     """Completion of one collective: ``wait()`` orders the CURRENT stream behind it (no host blocking)."""
 
-    __slots__ = ("event",)
+    __slots__ = ("event", "device")
 
-    def __init__(self, event: torch.cuda.Event):
+    def __init__(self, event: torch.cuda.Event, device=None):
         self.event = event
+        self.device = device
 
     def wait(self) -> None:
-        torch.cuda.current_stream().wait_event(self.event)
+        torch.cuda.current_stream(self.device).wait_event(self.event)
 
 
 class NativeCommunicator:
@@ -59,7 +60,10 @@ class NativeCommunicator:
         self.lib = _lib.require()
         check(self.lib.ddl_comm_load(_rccl_path()), "ddl_comm_load (RCCL not found)")
         self.rank, self.world, self.device = rank, world, device
-        torch.cuda.set_device(device)
+        with device_of(device):             # ncclCommInitRank binds the CALLING THREAD's current device; restored after
+            self._init(rank, world, device, group, store)
+
+    def _init(self, rank, world, device, group, store) -> None:
         ident = (C.c_char * 128)()
         if rank == 0:
             check(self.lib.ddl_comm_unique_id(C.addressof(ident)), "ncclGetUniqueId")
@@ -102,7 +106,7 @@ class NativeCommunicator:
     def _done(self) -> _Handle:
         ev = torch.cuda.Event()
         ev.record(self.stream)
-        return _Handle(ev)
+        return _Handle(ev, self.device)
 
     @staticmethod
     def _dt(t: torch.Tensor) -> int:
@@ -112,31 +116,35 @@ class NativeCommunicator:
 
     # ------------------------------------------------------------------ collectives (asynchronous)
     def all_reduce(self, t: torch.Tensor, average: bool = True) -> _Handle:
-        st = self._enter()
-        check(self.lib.ddl_comm_all_reduce(self._comm, t.data_ptr(), t.data_ptr(), t.numel(), self._dt(t), int(average),
-                                           st), "ncclAllReduce")
-        return self._done()
+        with device_of(self.device):
+            st = self._enter()
+            check(self.lib.ddl_comm_all_reduce(self._comm, t.data_ptr(), t.data_ptr(), t.numel(), self._dt(t),
+                                               int(average), st), "ncclAllReduce")
+            return self._done()
 
     def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, average: bool = True) -> _Handle:
         if inp.numel() != out.numel() * self.world or inp.dtype != out.dtype:
             raise ValueError("reduce_scatter: input must hold world x output elements of the same dtype")
-        st = self._enter()
-        check(self.lib.ddl_comm_reduce_scatter(self._comm, inp.data_ptr(), out.data_ptr(), out.numel(), self._dt(out),
-                                               int(average), st), "ncclReduceScatter")
-        return self._done()
+        with device_of(self.device):
+            st = self._enter()
+            check(self.lib.ddl_comm_reduce_scatter(self._comm, inp.data_ptr(), out.data_ptr(), out.numel(),
+                                                   self._dt(out), int(average), st), "ncclReduceScatter")
+            return self._done()
 
     def all_gather(self, out: torch.Tensor, inp: torch.Tensor) -> _Handle:
         if out.numel() != inp.numel() * self.world or inp.dtype != out.dtype:
             raise ValueError("all_gather: output must hold world x input elements of the same dtype")
-        st = self._enter()
-        check(self.lib.ddl_comm_all_gather(self._comm, inp.data_ptr(), out.data_ptr(), inp.numel(), self._dt(inp), st),
-              "ncclAllGather")
-        return self._done()
+        with device_of(self.device):
+            st = self._enter()
+            check(self.lib.ddl_comm_all_gather(self._comm, inp.data_ptr(), out.data_ptr(), inp.numel(), self._dt(inp),
+                                               st), "ncclAllGather")
+            return self._done()
 
     def broadcast(self, t: torch.Tensor, root: int = 0) -> _Handle:
-        st = self._enter()
-        check(self.lib.ddl_comm_broadcast(self._comm, t.data_ptr(), t.numel(), self._dt(t), root, st), "ncclBroadcast")
-        return self._done()
+        with device_of(self.device):
+            st = self._enter()
+            check(self.lib.ddl_comm_broadcast(self._comm, t.data_ptr(), t.numel(), self._dt(t), root, st), "ncclBroadcast")
+            return self._done()
 
     def barrier(self) -> None:
         """All ranks have enqueued everything before this call AND it has finished on every GPU: a one-element

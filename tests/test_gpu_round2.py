@@ -326,3 +326,27 @@ def test_conv1d_k1_relu_front_matches_torch(B):
     (conv(x) * (y.detach().float() > 0)).backward(dy.float())       # same gate as the kernel's own bf16 output
     _close(gw, conv.weight.grad, rtol=1e-2, atol=1e-2 * conv.weight.grad.abs().max().item(), what="conv1d dW")
     _close(gb, conv.bias.grad, rtol=1e-2, atol=1e-2 * conv.bias.grad.abs().max().item(), what="conv1d db")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,HW,Kc", [(32, 64, 56, 256), (16, 128, 28, 512), (8, 72, 14, 96), (4, 512, 7, 2048)])
+def test_conv1x1_with_input_batchnorm_applied_in_the_kernel_matches_fp32(N, C, HW, Kc):
+    """The bn2 -> conv3 fusion experiment (bench/inbn_probe.py, docs/STATUS.md): scale/shift/ReLU applied to the raw
+    producer output inside the ring kernel; y and its BatchNorm statistics against plain fp32."""
+    from distributed_deep_learning_amd.ops import kernels as K
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(11)
+    z = _rand_act((N, C, HW, HW), 12)
+    w = (torch.randn((Kc, C, 1, 1), generator=g) / C ** 0.5).to(dev)
+    scale = (torch.rand(C, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(C, generator=g) * 0.3).to(dev)
+    wk, _ = K.filter_repack(w.contiguous(memory_format=CL))
+    y, slab = K.conv1x1_fwd_inbn(z, wk, scale, shift)
+    a = F.relu(z.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(torch.bfloat16).float()
+    ref = F.conv2d(a, wk.float().permute(0, 3, 1, 2))
+    _close(y, ref, what="conv1x1_fwd_inbn y")
+    sums = K.slab_sums(slab)
+    n = N * HW * HW
+    _close(sums[0] / n, ref.mean((0, 2, 3)), what="conv1x1_fwd_inbn mean")
+    _close(sums[1] / n, (ref * ref).mean((0, 2, 3)), what="conv1x1_fwd_inbn mean square")
