@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--batches", default="32,512,4096")
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--workloads", default="cnn,lstm,mlp")
+    ap.add_argument("--ours-only", action="store_true", help="skip the stock columns (profiling runs)")
     a = ap.parse_args()
     print(f"{'workload':>8} {'batch':>6} | {'ours eager':>18} | {'ours hipGraph':>18} | {'stock fp32 eager':>18} | "
           f"{'stock bf16 autocast':>19} | vs fp32 | vs bf16", flush=True)
@@ -167,6 +168,9 @@ def main():
             except Exception as e:                     # noqa: BLE001 - report and go on
                 print(f"   graph capture failed for {name}: {type(e).__name__}: {e}", flush=True)
                 tg = float("nan")
+            if a.ours_only:
+                print(f"{name:>8} {B:>6} | eager {te:7.3f} ms | hipGraph {tg:7.3f} ms", flush=True)
+                continue
             ts = stock(x, y, crit_s, opt_kind, factory, a.steps)
             try:
                 tb = stock(x, y, crit_s, opt_kind, factory, a.steps, amp=True)

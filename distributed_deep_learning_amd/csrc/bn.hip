@@ -28,6 +28,11 @@ struct RowMap {
   int c8;     // C / 8
   int M;      // rows
   int C;
+  // Channel WINDOWS of a wider buffer (dense blocks, csrc/eltwise.hip copy_channels): the BN input x may have a row
+  // pitch ldx > C, the input gradient dx a pitch ldo > C and may be ACCUMULATED into what is there (acc).  Everything
+  // else (dy, y, masks, residuals) is dense [M][C].
+  int ldx, ldo, acc;
+  const bf16_t* acc_src;   // acc: dx = acc_src[same window position] + (this BN's input gradient); may alias dx
 };
 
 static inline RowMap make_rowmap(int M, int C) {
@@ -37,6 +42,7 @@ static inline RowMap make_rowmap(int M, int C) {
   r.rp = 256 / r.cpb;
   r.M = M;
   r.C = C;
+  r.ldx = C; r.ldo = C; r.acc = 0; r.acc_src = nullptr;
   return r;
 }
 
@@ -70,9 +76,9 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const bf16_t* __restrict_
   if (active) {
     // pivot: the first row this block visits (the same for every row group of a column)
     const int prow = min((int)(blockIdx.x * rm.rp), rm.M - 1);
-    unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)prow * rm.C + (size_t)chunk * 8), k);
+    unpack8(*reinterpret_cast<const u32x4*>(x + (size_t)prow * rm.ldx + (size_t)chunk * 8), k);
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
-      const u32x4 v = ld_stream(x + (size_t)row * rm.C + (size_t)chunk * 8);
+      const u32x4 v = ld_stream(x + (size_t)row * rm.ldx + (size_t)chunk * 8);
       float f[8];
       unpack8(v, f);
 #pragma unroll
@@ -206,7 +212,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
     const int row = rm.M - 1 - r0;
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-    const u32x4 v = ld_stream(x + off);
+    const u32x4 v = ld_stream(x + (size_t)row * rm.ldx + (size_t)chunk * 8);
     float f[8];
     unpack8(v, f);
 #pragma unroll
@@ -321,12 +327,99 @@ __device__ __forceinline__ void pooled_grad8(const bf16_t* __restrict__ dp, cons
 }
 
 // ---------------------------------------------------------------- backward: reductions
+// Fused finalize of the backward sums (C <= 512, one column group): the LAST block to finish folds the slab and writes
+// dgamma / dbeta and the three coefficient vectors of the apply pass - no finalize launch between the two passes.
+// Same last-arriver hand-off as conv_epilogue.h (drain atomics -> barrier -> relaxed agent ticket; the last arriver runs
+// one agent-scope acquire, waits, barriers, reads).  `nslots` slots are used by this launch (fewer than BN_SLOTS, so
+// that the fold is ONE batch of at most 16 loads per thread: bwd_fin_slots); counter == null: plain reduction into BN_SLOTS slots.
+struct BwdFin {
+  unsigned* counter;
+  int nslots;
+  float count;
+  const float* gamma;
+  float* dgamma;
+  float* dbeta;
+  int accumulate;
+  float* coefA;
+  float* coefB;
+  float* coefC;
+};
+
+__device__ __forceinline__ void bn_bwd_fused_finalize(float* __restrict__ slab_f, float* red, const BwdFin& f, int C,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd) {
+  const int tid = threadIdx.x;
+  unsigned* const flag = reinterpret_cast<unsigned*>(red + 256 * 16 - 4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's slab atomics have been performed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(f.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (t == gridDim.x - 1u) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0u) return;
+  double* const slab = reinterpret_cast<double*>(slab_f);
+  double* const part = reinterpret_cast<double*>(red);           // [G][2][C] (C <= 256) - 16 KB of `red` at most
+  int G = C < 256 ? 256 / C : 1;
+  if (G > f.nslots) G = f.nslots;
+  for (int c0 = 0; c0 < C; c0 += 256) {                          // one trip for C <= 256, two for C = 512 (G == 1)
+    const int item = c0 + tid;
+    const int c = C < 256 ? tid % C : item, g = C < 256 ? tid / C : 0;
+    double a = 0.0, b = 0.0;
+    if (c < C && g < G) {
+      double va[8], vb[8];                                       // nslots / G <= 8 (see bwd_fin_slots)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sl = g + G * i;
+        const bool ok = sl < f.nslots;
+        va[i] = ok ? slab[((size_t)sl * 2 + 0) * C + c] : 0.0;
+        vb[i] = ok ? slab[((size_t)sl * 2 + 1) * C + c] : 0.0;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sl = g + G * i;
+        if (sl < f.nslots) {
+          a += va[i]; b += vb[i];
+          slab[((size_t)sl * 2 + 0) * C + c] = 0.0;
+          slab[((size_t)sl * 2 + 1) * C + c] = 0.0;
+        }
+      }
+    }
+    if (G > 1) {
+      if (c < C && g < G) { part[(g * 2 + 0) * C + c] = a; part[(g * 2 + 1) * C + c] = b; }
+      __syncthreads();
+      if (tid < C) {
+        a = 0.0; b = 0.0;
+        for (int q = 0; q < G; ++q) { a += part[(q * 2 + 0) * C + tid]; b += part[(q * 2 + 1) * C + tid]; }
+      }
+    }
+    if (c < C && g == 0) {
+      const float sg = (float)a, sgx = (float)b;
+      if (f.accumulate) { f.dgamma[c] += sgx; f.dbeta[c] += sg; }      // straight into the arena
+      else              { f.dgamma[c] = sgx;  f.dbeta[c] = sg; }
+      const float gm = f.gamma ? f.gamma[c] : 1.f;
+      const float sc = gm * invstd[c];
+      const float mg = sg / f.count, mgx = sgx / f.count;
+      f.coefA[c] = sc;
+      f.coefB[c] = -sc * mgx * invstd[c];
+      f.coefC[c] = -sc * mg + sc * mgx * invstd[c] * mean[c];
+    }
+  }
+  if (tid == 0) *f.counter = 0u;                                 // ready for the next launch
+}
+
 // POOL: dy / mask are the POOLED gradient and the argmax bytes of bn_relu_maxpool_fwd_kernel (see pooled_grad8)
-template <bool RELU, bool POOL = false>
+// FUSE: the last block finalizes (bn_bwd_fused_finalize); a separate instantiation so that the plain reduction keeps its
+// register budget (8 waves per SIMD - with the fold inlined it dropped to 7 and the large layers ran 16 % slower).
+template <bool RELU, bool POOL = false, bool FUSE = false, bool WIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ slab,
-                                                            RowMap rm, PoolMap pm = PoolMap()) {
+                                                            RowMap rm, BwdFin fin, PoolMap pm = PoolMap()) {
   __shared__ float red[256 * 16];
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
@@ -341,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     for (int q = 0; q < 8; ++q) { mu[q] = mean[chunk * 8 + q]; is[q] = invstd[chunk * 8 + q]; }
     for (int row = blockIdx.x * rm.rp + rg; row < rm.M; row += gridDim.x * rm.rp) {
       const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-      const u32x4 xv = ld_stream(x + off);
+      const u32x4 xv = ld_stream(x + (WIN ? (size_t)row * rm.ldx + (size_t)chunk * 8 : off));
       float g[8], xf[8];
       unpack8(xv, xf);
       if (POOL) {
@@ -370,9 +463,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     float s = 0.f;
     for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
     const int which = e >> 3, q = e & 7;
-    const int slot = blockIdx.x % BN_SLOTS;
+    const int slot = FUSE ? (int)(blockIdx.x % (unsigned)fin.nslots) : (int)(blockIdx.x % BN_SLOTS);
     slab_add(slab, ((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q, (double)s);
   }
+  if constexpr (FUSE) bn_bwd_fused_finalize(slab, red, fin, rm.C, mean, invstd);
 }
 
 // slab -> dgamma, dbeta and the three per-channel coefficients of dx = A*g + B*x + Cc
@@ -398,7 +492,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(float* __restrict_
   coefC[c] = -sc * mg + sc * mgx * invstd[c] * mean[c];
 }
 
-template <bool RELU, bool DRES, bool POOL = false>
+// WIN: x and dx are channel windows of wider buffers (pitches rm.ldx / rm.ldo) and dx may be accumulated (rm.acc_src);
+// its own instantiation so the dense kernel keeps one offset for all four streams (and 8 waves per SIMD).
+template <bool RELU, bool DRES, bool POOL = false, bool WIN = false>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, const unsigned char* __restrict__ mask,
                                                            const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
                                                            bf16_t* __restrict__ dres, const float* __restrict__ coefA,
@@ -415,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   for (int r0 = blockIdx.x * rm.rp + rg; r0 < rm.M; r0 += gridDim.x * rm.rp) {
     const int row = rm.M - 1 - r0;          // tail first: what the reduce pass read last is still cached
     const size_t off = (size_t)row * rm.C + (size_t)chunk * 8;
-    const u32x4 xv = ld_stream(x + off);
+    const u32x4 xv = ld_stream(x + (WIN ? (size_t)row * rm.ldx + (size_t)chunk * 8 : off));
     float g[8], xf[8];
     unpack8(xv, xf);
     if (POOL) {
@@ -433,7 +529,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     float o[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = a[q] * g[q] + b[q] * xf[q] + c[q];
-    *reinterpret_cast<u32x4*>(dx + off) = pack8(o);
+    if constexpr (WIN) {
+      const size_t doff = (size_t)row * rm.ldo + (size_t)chunk * 8;
+      if (rm.acc) {                          // gradient of a shared feature map: add to what later layers left there
+        float old[8];
+        unpack8(*reinterpret_cast<const u32x4*>(rm.acc_src + doff), old);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] += old[q];
+      }
+      *reinterpret_cast<u32x4*>(dx + doff) = pack8(o);
+    } else {
+      *reinterpret_cast<u32x4*>(dx + off) = pack8(o);
+    }
   }
 }
 
@@ -564,15 +671,76 @@ extern "C" int ddl_slab_fold(float* slab, int C, float* out, int accumulate, voi
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- statistics of a growing feature map (dense blocks)
+// Every channel of a dense block's buffer is produced once (block input, then one conv window per layer) and read by
+// every later layer's BatchNorm.  Its batch statistics do not depend on the reader, so they are taken ONCE - in the
+// epilogue of the producing conv - folded into a per-block totals table tot[2][Ctot] (fp64, NOT self-cleaning), and each
+// reader finalizes its own (gamma, beta, running stats) from the prefix of that table: no statistics pass per layer.
+__global__ __launch_bounds__(256) void slab_fold_totals_kernel(float* __restrict__ slab, int C, double* __restrict__ tot,
+                                                               int Ctot, int c0) {
+  double s1, s2;
+  slab_fold(slab, BN_SLOTS, C, s1, s2);
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (threadIdx.x < 64 && c < C) { tot[c0 + c] = s1; tot[(size_t)Ctot + c0 + c] = s2; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_totals_kernel(const double* __restrict__ tot, int Ctot, int C, float count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float momentum, float eps, float* __restrict__ mean, float* __restrict__ invstd,
+                                   float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double mud = tot[c] / (double)count;
+  const float mu = (float)mud;
+  const float var = fmaxf((float)(tot[(size_t)Ctot + c] / (double)count - mud * mud), 0.f);
+  const float is = rsqrtf(var + eps);
+  mean[c] = mu;
+  invstd[c] = is;
+  const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+  scale[c] = g * is;
+  shift[c] = b - mu * g * is;
+  if (running_mean) {
+    const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+extern "C" int ddl_slab_fold_totals(float* slab, int C, void* tot, int Ctot, int c0, void* stream) {
+  if (C <= 0 || c0 < 0 || c0 + C > Ctot || slab == nullptr || tot == nullptr) return -1;
+  hipLaunchKernelGGL(slab_fold_totals_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, slab, C,
+                     (double*)tot, Ctot, c0);
+  return (int)hipGetLastError();
+}
+
+extern "C" int ddl_bn_finalize_totals(const void* tot, int Ctot, int C, float count, const float* gamma, const float* beta,
+                                      float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                                      float* invstd, float* scale, float* shift, void* stream) {
+  if (C <= 0 || C > Ctot || tot == nullptr) return -1;
+  hipLaunchKernelGGL(bn_finalize_totals_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     (const double*)tot, Ctot, C, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd,
+                     scale, shift);
+  return (int)hipGetLastError();
+}
+
 extern "C" int ddl_bn_slots() { return BN_SLOTS; }
 
 // slab: [BN_SLOTS][2][C] fp64 workspace (passed as float*), must be ZERO on entry (finalize re-zeroes it: self-cleaning).
-extern "C" int ddl_bn_stats(const void* x, float* slab, int M, int C, void* stream) {
-  if (C % 8 != 0 || M <= 0) return -1;
+static inline bool pitch_ok(const void* p, int ld, int C) { return ld >= C && ld % 8 == 0 && ((uintptr_t)p & 15) == 0; }
+
+// ldx: row pitch of x in elements (a channel window [M][C] of a wider [M][ldx] buffer; ldx == C is the dense case)
+extern "C" int ddl_bn_stats_ld(const void* x, int ldx, float* slab, int M, int C, void* stream) {
+  if (C % 8 != 0 || M <= 0 || !pitch_ok(x, ldx, C)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const RowMap rm = make_rowmap(M, C);
+  RowMap rm = make_rowmap(M, C);
+  rm.ldx = ldx;
   hipLaunchKernelGGL(bn_stats_kernel, rowmap_grid(rm), dim3(256), 0, st, (const bf16_t*)x, slab, rm);
   return (int)hipGetLastError();
+}
+
+extern "C" int ddl_bn_stats(const void* x, float* slab, int M, int C, void* stream) {
+  return ddl_bn_stats_ld(x, C, slab, M, C, stream);
 }
 
 extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, const float* gamma,
@@ -584,13 +752,14 @@ extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, cons
 }
 
 // mask (optional, only written when relu): [M][C/8] bytes, bit q of byte (row, chunk) = (y[row][chunk*8+q] > 0)
-extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
-                            const float* shift, const float* res_scale, const float* res_shift, int M, int C, int relu,
-                            void* stream) {
-  if (C % 8 != 0 || M <= 0) return -1;
+static int bn_apply_impl(const void* x, int ldx, const void* res, void* y, void* mask, const float* scale,
+                         const float* shift, const float* res_scale, const float* res_shift, int M, int C, int relu,
+                         void* stream) {
+  if (C % 8 != 0 || M <= 0 || !pitch_ok(x, ldx, C)) return -1;
   if ((res_scale != nullptr) != (res_shift != nullptr) || (res_scale != nullptr && res == nullptr)) return -2;
   const float* rs = res_scale; const float* rh = res_shift;
-  const RowMap rm = make_rowmap(M, C);
+  RowMap rm = make_rowmap(M, C);
+  rm.ldx = ldx;
   const dim3 grid = rowmap_grid(rm, apply_grid_cap());
   hipStream_t st = (hipStream_t)stream;
   const bf16_t* xp = (const bf16_t*)x; const bf16_t* rp = (const bf16_t*)res; bf16_t* yp = (bf16_t*)y;
@@ -605,27 +774,85 @@ extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask,
   return (int)hipGetLastError();
 }
 
+extern "C" int ddl_bn_apply(const void* x, const void* res, void* y, void* mask, const float* scale,
+                            const float* shift, const float* res_scale, const float* res_shift, int M, int C, int relu,
+                            void* stream) {
+  return bn_apply_impl(x, C, res, y, mask, scale, shift, res_scale, res_shift, M, C, relu, stream);
+}
+
+// y[M][C] (dense) = act(x * scale + shift) for a channel window x of a [M][ldx] buffer
+extern "C" int ddl_bn_apply_ld(const void* x, int ldx, void* y, void* mask, const float* scale, const float* shift, int M,
+                               int C, int relu, void* stream) {
+  return bn_apply_impl(x, ldx, nullptr, y, mask, scale, shift, nullptr, nullptr, M, C, relu, stream);
+}
+
 // Full backward.  slab must be ZERO on entry (it is left zero again).  mask: the [M][C/8] ReLU bit mask written by ddl_bn_apply (required when relu).  slab: [BN_SLOTS][2][C] workspace; coef: [3][C] workspace.  dres may be null.
-extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, const float* gamma, const float* mean,
-                               const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
-                               float* coef, int M, int C, int relu, int accumulate, int presummed, void* stream) {
-  if (C % 8 != 0 || M <= 0) return -1;
+// Slots for a fused backward reduce: 16 / 16 / 8 / 4 for C <= 64 / 128 / 256 / 512 - with 256 / C slot groups of
+// threads (one for C >= 256) every thread folds at most 8 slots.  0: not fused (wide layers: one block folding 1024+
+// channels would take longer than the launch it saves).
+// DDL_FUSED_FINALIZE: 1 (default) fuses for tensors of at most 16 MiB - where launches are latency-bound; on a saturated
+// chip the drained atomics and the serial fold cost more than the launch they replace (conv_igemm.hip, docs/STATUS.md).
+static inline int bwd_fin_slots(int C, const dim3& grid, long long M) {
+  static const int fused = [] { const char* e = getenv("DDL_FUSED_FINALIZE"); return e ? atoi(e) : 1; }();
+  if (!fused || C > 512 || grid.y != 1) return 0;
+  if (fused == 1 && M * C * 2 > (16ll << 20)) return 0;
+  int n = 2048 / C;
+  if (n > 16) n = 16;
+  if (n < 4) n = 4;
+  const int G = C < 256 ? 256 / C : 1;
+  while (n > 8 * G) n >>= 1;
+  return n;
+}
+
+static int bn_backward_impl(const void* dy, const void* mask, const void* x, int ldx, const float* gamma, const float* mean,
+                            const float* invstd, void* dx, int ldo, const void* acc_src, void* dres, float* dgamma, float* dbeta,
+                            float* slab, float* coef, int M, int C, int relu, int accumulate, int presummed, void* stream) {
+  if (C % 8 != 0 || M <= 0 || !pitch_ok(x, ldx, C) || !pitch_ok(dx, ldo, C)) return -1;
   hipStream_t st = (hipStream_t)stream;
-  const RowMap rm = make_rowmap(M, C);
+  RowMap rm = make_rowmap(M, C);
+  if (acc_src != nullptr && ((uintptr_t)acc_src & 15) != 0) return -1;
+  rm.ldx = ldx; rm.ldo = ldo; rm.acc = acc_src != nullptr; rm.acc_src = (const bf16_t*)acc_src;
   const dim3 grid = rowmap_grid(rm);
   const bf16_t* dyp = (const bf16_t*)dy; const unsigned char* yp = (const unsigned char*)mask; const bf16_t* xp = (const bf16_t*)x;
   if (relu && mask == nullptr) return -2;
   // presummed: the producer of dy (a dgrad epilogue) already left sum(g), sum(g*x) in the slab: no reduction pass
-  if (!presummed) {
-    if (relu) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
-    else      hipLaunchKernelGGL((bn_bwd_reduce_kernel<false>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, slab, rm);
-  }
   float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
-                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC, presummed ? 1 : 0);
+  BwdFin fin{};
+  fin.nslots = BN_SLOTS;
+  const int fslots = presummed ? 0 : bwd_fin_slots(C, grid, (long long)M);
+  if (fslots > 0) {       // the arrival counter lives behind the three coefficient vectors (kernels.new_slab: 4C floats)
+    fin.counter = reinterpret_cast<unsigned*>(coef + 3 * (size_t)C);
+    fin.nslots = fslots; fin.count = (float)M; fin.gamma = gamma; fin.dgamma = dgamma; fin.dbeta = dbeta;
+    fin.accumulate = accumulate; fin.coefA = cA; fin.coefB = cB; fin.coefC = cC;
+  }
+  const bool win = ldx != C || ldo != C || acc_src != nullptr;
+  if (win && dres != nullptr) return -3;
+#define DDL_REDUCE(RELU_, FUSE_, WIN_)                                                                                   \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<RELU_, false, FUSE_, WIN_>), grid, dim3(256), 0, st, dyp, yp, xp, mean, invstd, \
+                     slab, rm, fin)
+  if (!presummed) {
+    const int sel = (relu ? 4 : 0) | (fslots > 0 ? 2 : 0) | (win ? 1 : 0);
+    switch (sel) {
+      case 0: DDL_REDUCE(false, false, false); break;
+      case 1: DDL_REDUCE(false, false, true); break;
+      case 2: DDL_REDUCE(false, true, false); break;
+      case 3: DDL_REDUCE(false, true, true); break;
+      case 4: DDL_REDUCE(true, false, false); break;
+      case 5: DDL_REDUCE(true, false, true); break;
+      case 6: DDL_REDUCE(true, true, false); break;
+      default: DDL_REDUCE(true, true, true); break;
+    }
+  }
+#undef DDL_REDUCE
+  if (fslots == 0)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
+                       mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC, presummed ? 1 : 0);
   bf16_t* dxp = (bf16_t*)dx; bf16_t* drp = (bf16_t*)dres;
   const dim3 agrid = rowmap_grid(rm, apply_grid_cap());
-  if (relu) {
+  if (win) {
+    if (relu) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, false, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+    else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false, false, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
+  } else if (relu) {
     if (dres) hipLaunchKernelGGL((bn_bwd_apply_kernel<true, true>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
     else      hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   } else {
@@ -633,6 +860,24 @@ extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, 
     else      hipLaunchKernelGGL((bn_bwd_apply_kernel<false, false>), agrid, dim3(256), 0, st, dyp, yp, xp, dxp, drp, cA, cB, cC, rm);
   }
   return (int)hipGetLastError();
+}
+
+extern "C" int ddl_bn_backward(const void* dy, const void* mask, const void* x, const float* gamma, const float* mean,
+                               const float* invstd, void* dx, void* dres, float* dgamma, float* dbeta, float* slab,
+                               float* coef, int M, int C, int relu, int accumulate, int presummed, void* stream) {
+  return bn_backward_impl(dy, mask, x, C, gamma, mean, invstd, dx, C, nullptr, dres, dgamma, dbeta, slab, coef, M, C, relu,
+                          accumulate, presummed, stream);
+}
+
+// Backward for a channel window: x is a window of a [M][ldx] buffer, dx goes to a window of a [M][ldo] buffer.  With
+// acc_src (same window position in a buffer of the same pitch, may BE dx) the result is acc_src + gradient: the shared
+// feature map of a dense block collects one gradient per reader, the first reader taking the upstream gradient as source.
+extern "C" int ddl_bn_backward_ld(const void* dy, const void* mask, const void* x, int ldx, const float* gamma,
+                                  const float* mean, const float* invstd, void* dx, int ldo, const void* acc_src, float* dgamma,
+                                  float* dbeta, float* slab, float* coef, int M, int C, int relu, int accumulate,
+                                  void* stream) {
+  return bn_backward_impl(dy, mask, x, ldx, gamma, mean, invstd, dx, ldo, acc_src, nullptr, dgamma, dbeta, slab, coef, M, C,
+                          relu, accumulate, 0, stream);
 }
 
 // Backward of two BatchNorms sharing dy (+ mask): see bn_bwd_reduce2_kernel.  Every per-BN argument comes as a / b.
@@ -693,10 +938,20 @@ extern "C" int ddl_bn_relu_maxpool_bwd(const void* dp, const void* idx, const vo
   const dim3 grid = rowmap_grid(rm);
   const PoolMap pm = make_poolmap(H, W, P, Q, k, stride, pad);
   const bf16_t* dpp = (const bf16_t*)dp; const unsigned char* ip = (const unsigned char*)idx; const bf16_t* xp = (const bf16_t*)x;
-  hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), grid, dim3(256), 0, st, dpp, ip, xp, mean, invstd, slab, rm, pm);
   float* cA = coef; float* cB = coef + C; float* cC = coef + 2 * (size_t)C;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
-                     mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
+  BwdFin fin{};
+  fin.nslots = BN_SLOTS;
+  const int fslots = bwd_fin_slots(C, grid, (long long)M);
+  if (fslots > 0) {
+    fin.counter = reinterpret_cast<unsigned*>(coef + 3 * (size_t)C);
+    fin.nslots = fslots; fin.count = (float)M; fin.gamma = gamma; fin.dgamma = dgamma; fin.dbeta = dbeta;
+    fin.accumulate = accumulate; fin.coefA = cA; fin.coefB = cB; fin.coefC = cC;
+  }
+  if (fslots > 0) hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true, true>), grid, dim3(256), 0, st, dpp, ip, xp, mean, invstd, slab, rm, fin, pm);
+  else            hipLaunchKernelGGL((bn_bwd_reduce_kernel<true, true>), grid, dim3(256), 0, st, dpp, ip, xp, mean, invstd, slab, rm, fin, pm);
+  if (fslots == 0)
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
+                       mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
   hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), grid, dim3(256), 0, st, dpp, ip, xp, (bf16_t*)dx,
                      (bf16_t*)nullptr, cA, cB, cC, rm, pm);
   return (int)hipGetLastError();

@@ -6,6 +6,85 @@
 #include "common.h"
 #include "conv_params.h"
 
+// Last-arriver finalize of the forward statistics of channel tile [n0, n0 + BN).  Every block of the tile column has
+// added its partial sums to the slab with memory-side fp64 atomics; the hand-off is the counter form of the guide's
+// inter-workgroup protocol: each wave drains its atomics (vmcnt 0) -> workgroup barrier -> ONE relaxed agent-scope
+// ticket add; the block that draws the last ticket runs ONE agent-scope acquire (invalidates this CU's L1), waits for
+// it, barriers, and only then reads the slab.  No block ever waits on another: the grid always drains.
+template <int BN, int LDS_BYTES>
+__device__ __forceinline__ void conv_fused_bn_finalize(const ConvParams& p, char* smem, int n0, int tid) {
+  constexpr int G = 512 / BN;                   // slot groups (4 or 8), PER slots each
+  constexpr int PER = DDL_BN_SLOTS / G;
+  constexpr int PART_BYTES = G * 2 * BN * 8;
+  static_assert(PART_BYTES + 16 <= LDS_BYTES, "finalize scratch must fit in the epilogue space");
+  const int tile_n = n0 / BN;
+  unsigned* const flag = reinterpret_cast<unsigned*>(smem + PART_BYTES);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's slab atomics have been performed
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(p.fin.counter + tile_n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned last = (t == (unsigned)p.tiles_m - 1u) ? 1u : 0u;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  if (*flag == 0u) return;
+  double* const slab = reinterpret_cast<double*>(p.stats);
+  const int c = tid % BN, g = tid / BN, ch = n0 + c;
+  double a = 0.0, b = 0.0;
+  if (ch < p.OC) {
+    // 8 slots (16 loads) in flight per thread and round trip: more would push the kernel past the 128 VGPRs that let
+    // two blocks share a CU
+    constexpr int CH = PER < 8 ? PER : 8;
+#pragma unroll 1
+    for (int i0 = 0; i0 < PER; i0 += CH) {
+      double va[CH], vb[CH];
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const size_t s = (size_t)(g + G * (i0 + i));
+        va[i] = slab[(s * 2 + 0) * p.OC + ch];
+        vb[i] = slab[(s * 2 + 1) * p.OC + ch];
+      }
+#pragma unroll
+      for (int i = 0; i < CH; ++i) {
+        const size_t s = (size_t)(g + G * (i0 + i));
+        a += va[i]; b += vb[i];
+        slab[(s * 2 + 0) * p.OC + ch] = 0.0;      // self-cleaning, like the stand-alone finalize
+        slab[(s * 2 + 1) * p.OC + ch] = 0.0;
+      }
+    }
+  }
+  double* const part = reinterpret_cast<double*>(smem);          // [G][2][BN]
+  part[(g * 2 + 0) * BN + c] = a;
+  part[(g * 2 + 1) * BN + c] = b;
+  __syncthreads();
+  if (tid == 0) p.fin.counter[tile_n] = 0u;                      // ready for the next launch
+  if (tid < BN && ch < p.OC) {
+    double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+    for (int q = 0; q < G; ++q) { s1 += part[(q * 2 + 0) * BN + tid]; s2 += part[(q * 2 + 1) * BN + tid]; }
+    const float count = p.fin.count;
+    const double mud = s1 / (double)count;
+    const float mu = (float)mud;
+    const float var = fmaxf((float)(s2 / (double)count - mud * mud), 0.f);
+    const float is = rsqrtf(var + p.fin.eps);
+    const float gm = p.fin.gamma ? p.fin.gamma[ch] : 1.f, bt = p.fin.beta ? p.fin.beta[ch] : 0.f;
+    float* const vec = p.fin.vec;
+    vec[ch] = mu;
+    vec[(size_t)p.OC + ch] = is;
+    vec[2 * (size_t)p.OC + ch] = gm * is;
+    vec[3 * (size_t)p.OC + ch] = bt - mu * gm * is;
+    if (p.fin.running_mean != nullptr) {
+      const float unbiased = count > 1.f ? var * count / (count - 1.f) : var;
+      p.fin.running_mean[ch] = (1.f - p.fin.momentum) * p.fin.running_mean[ch] + p.fin.momentum * mu;
+      p.fin.running_var[ch] = (1.f - p.fin.momentum) * p.fin.running_var[ch] + p.fin.momentum * unbiased;
+    }
+  }
+}
+
 template <int BN, int MODE, int EPI, int LDS_BYTES>
 __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* smem, f32x4 (&acc)[BN / 32][4], int tile_m,
                                                   int m0, int n0, int tid, int lane, int wm, int wn) {
@@ -116,7 +195,7 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
 #pragma unroll
         for (int q = 0; q < 8; ++q) { s1[q] += g[q]; s2[q] += g[q] * z[q]; }
       }
-      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.out_ld + (size_t)ncol) = vo;
       if ((EPI & 2) && MODE != 1) {
         float f[8];
         unpack8(v, f);
@@ -161,5 +240,7 @@ __device__ __forceinline__ void conv_epilogue_256(const ConvParams& p, char* sme
         slab_add(p.stats, (sbase + 1) * (size_t)p.OC + n0 + col, sxx);
       }
     }
+    // EPI & 16: its own instantiation, so layers that do not fuse (large tensors, docs/STATUS.md) run the lean epilogue
+    if constexpr (MODE != 1 && (EPI & 16) != 0) conv_fused_bn_finalize<BN, LDS_BYTES>(p, smem, n0, tid);
   }
 }

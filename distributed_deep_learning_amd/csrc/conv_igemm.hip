@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int q = 0; q < 8; ++q) f[q] += a[q];
         vo = pack8(f);
       }
-      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.OC + (size_t)ncol) = vo;
+      *reinterpret_cast<u32x4*>(p.out + opix * (size_t)p.out_ld + (size_t)ncol) = vo;
       if (p.stats != nullptr) {
         float f[8];
         unpack8(v, f);
@@ -330,11 +330,17 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   return launch_conv<128, 128, MODE>(p, st);
 }
 
+extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                               float* invstd, float* scale, float* shift, void* stream);     // bn.hip
+
 static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
                            const void* addend, const void* addend_mask, int addend_step, const void* bnz,
                            const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
-                           int pad, int relu, void* stream, const float* in_scale, const float* in_shift) {
+                           int pad, int relu, void* stream, const float* in_scale, const float* in_shift, int out_ld = 0,
+                           const BnFin* fin = nullptr) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
+  if (out_ld != 0 && (mode != 0 || out_ld < OC || out_ld % 8 != 0 || ((uintptr_t)out & 15) != 0)) return -12;
   if (N <= 0 || OH <= 0 || OW <= 0 || IH <= 0 || IW <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0) return -2;
   const long long M = (long long)N * OH * OW;
   if (M >= (1ll << 31) || (long long)N * IH * IW >= (1ll << 31)) return -3;
@@ -353,6 +359,22 @@ static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out
   p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask; p.bn_flags = bn_flags;
   if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale != nullptr && mode != 0)) return -11;
   p.in_scale = in_scale; p.in_shift = in_shift;
+  p.out_ld = out_ld != 0 ? out_ld : OC;
+  p.fin = BnFin{};
+  p.fin_done = 0;
+  if (fin != nullptr) {
+    if (mode != 0 || stats == nullptr || fin->vec == nullptr) return -13;
+    p.fin = *fin;
+    p.fin.count = (float)M;
+    // arrival counters live in the slab's fp32 scratch rows, behind the three coefficient vectors of the backward pass
+    // Measured (docs/STATUS.md): the in-kernel finalize wins where launches are latency-bound (small tensors: -3..4 %
+    // step time on the reference CNN at batch 32 and ResNet-18/CIFAR) and LOSES on a saturated chip (+1.5 % on
+    // ResNet-50 at batch 512: every block drains its atomics before taking a ticket and the last block's serial fold
+    // runs at loaded-memory latency).  1 (default): fuse when the output is at most 16 MiB; 2: always; 0: never.
+    static const int fused = [] { const char* e = getenv("DDL_FUSED_FINALIZE"); return e ? atoi(e) : 1; }();
+    const bool fuse = fused == 2 || (fused == 1 && (size_t)M * (size_t)OC * 2 <= ((size_t)16 << 20));
+    p.fin.counter = fuse ? reinterpret_cast<unsigned*>(stats + (size_t)DDL_BN_SLOTS * 2 * OC * 2 + 3 * (size_t)OC) : nullptr;
+  }
   p.N = N; p.OH = OH; p.OW = OW; p.IH = IH; p.IW = IW; p.IC = IC; p.OC = OC; p.R = R; p.S = S;
   p.stride = stride; p.pad = pad; p.relu = relu;
   p.KredFull = R * S * IC;
@@ -364,7 +386,13 @@ static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out
     p.M = (int)M; p.Kred = p.KredFull;
     p.o_step = 1; p.o_ph = 0; p.o_pw = 0;
     p.r0 = 0; p.s0 = 0; p.t_step = 1; p.nR = R; p.nS = S;
-    return mode == 0 ? launch_any<0>(p, st) : launch_any<1>(p, st);
+    if (mode != 0) return launch_any<1>(p, st);
+    const int rc = launch_any<0>(p, st);
+    if (rc != 0 || fin == nullptr || p.fin_done) return rc;
+    // the kernel that ran has no fused finalize (register-staged fallback, or fusion switched off): separate launch
+    return ddl_bn_finalize(stats, DDL_BN_SLOTS, OC, (float)M, fin->gamma, fin->beta, fin->running_mean, fin->running_var,
+                           fin->momentum, fin->eps, fin->vec, fin->vec + OC, fin->vec + 2 * (size_t)OC,
+                           fin->vec + 3 * (size_t)OC, stream);
   }
   // dgrad with stride > 1: one dense launch per parity class of the input pixels
   bool any_empty = false;
@@ -412,4 +440,27 @@ extern "C" int ddl_conv_fwd_inbn(const void* in, const void* wmat, void* out, fl
   if (in_scale == nullptr || in_shift == nullptr || stats == nullptr || IC > 512) return -11;
   return conv_igemm_impl(0, in, wmat, out, nullptr, stats, nullptr, nullptr, 1, nullptr, nullptr, 0, N, H, W, H, W, IC, OC, 1,
                          1, 1, 0, 0, stream, in_scale, in_shift);
+}
+
+// Forward convolution writing its [pixels][OC] result into a channel window of a wider [pixels][out_ld] buffer
+// (`out` = address of the window's first channel; out_ld % 8 == 0).  The window's statistics go to `stats`.
+extern "C" int ddl_conv_fwd_ld(const void* in, const void* wmat, void* out, int out_ld, float* stats, int N, int OH, int OW,
+                               int IH, int IW, int IC, int OC, int R, int S, int stride, int pad, void* stream) {
+  return conv_igemm_impl(0, in, wmat, out, nullptr, stats, nullptr, nullptr, 1, nullptr, nullptr, 0, N, OH, OW, IH, IW, IC, OC,
+                         R, S, stride, pad, 0, stream, nullptr, nullptr, out_ld);
+}
+
+// Forward convolution + BatchNorm statistics + BatchNorm finalize as ONE launch where the kernel supports it: the last
+// block of every channel tile turns the slab into vec[4][OC] = (mean, invstd, scale, shift) and updates the running
+// statistics (conv_epilogue.h).  `slab` must be a zeroed [2*DDL_BN_SLOTS + 2][2][OC] fp32 workspace (kernels.new_slab)
+// and is left zero.  out_ld: 0 (dense) or the row pitch of a wider output buffer.
+extern "C" int ddl_conv_fwd_bn(const void* in, const void* wmat, void* out, int out_ld, float* slab, int N, int OH, int OW,
+                               int IH, int IW, int IC, int OC, int R, int S, int stride, int pad, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                               float* vec, void* stream) {
+  BnFin fin{};
+  fin.gamma = gamma; fin.beta = beta; fin.running_mean = running_mean; fin.running_var = running_var;
+  fin.momentum = momentum; fin.eps = eps; fin.vec = vec;
+  return conv_igemm_impl(0, in, wmat, out, nullptr, slab, nullptr, nullptr, 1, nullptr, nullptr, 0, N, OH, OW, IH, IW, IC, OC,
+                         R, S, stride, pad, 0, stream, nullptr, nullptr, out_ld, &fin);
 }

@@ -2,6 +2,19 @@
 #pragma once
 #include "common.h"
 
+// Fused BatchNorm finalize of a forward conv's output statistics (conv_epilogue.h): the LAST block to finish a channel
+// tile folds that tile's slab columns and writes mean / invstd / scale / shift (+ running statistics), so no separate
+// finalize launch sits between the conv and the BN apply pass.
+struct BnFin {
+  unsigned* counter;       // [tiles_n] arrival counters: zero on entry, left zero (null: no fused finalize)
+  float count, momentum, eps;
+  const float* gamma;
+  const float* beta;
+  float* running_mean;     // may be null
+  float* running_var;
+  float* vec;              // [4][OC]: mean, invstd, scale, shift
+};
+
 struct ConvParams {
   const bf16_t* in;
   const bf16_t* wmat;
@@ -36,6 +49,12 @@ struct ConvParams {
   // the normalised activation is never written or re-read (fp32 [IC] each, IC <= 512).
   const float* in_scale;
   const float* in_shift;
+  // forward only: row pitch of `out` in elements (>= OC, multiple of 8).  The tile is written into a channel window of
+  // a wider [pixels][out_ld] buffer (`out` already points at the window's first channel): a dense block's feature map
+  // grows in place, no concatenation copy.
+  int out_ld;
+  BnFin fin;
+  int fin_done;                           // set by a launcher whose kernel performs the fused finalize
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 

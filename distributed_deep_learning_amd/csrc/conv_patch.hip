@@ -216,7 +216,13 @@ int launch_patch(ConvParams& p, hipStream_t stream) {
 template <int BN>
 int dispatch_patch(ConvParams& p, int mode, hipStream_t stream) {
   if (mode == 0) {
-    if (p.stats != nullptr) return launch_patch<BN, 0, 2>(p, stream);
+    if (p.stats != nullptr) {
+      if (p.fin.counter != nullptr) {
+        p.fin_done = 1;
+        return launch_patch<BN, 0, 18>(p, stream);
+      }
+      return launch_patch<BN, 0, 2>(p, stream);
+    }
     if (p.bias != nullptr || p.relu) return launch_patch<BN, 0, 1>(p, stream);
     return launch_patch<BN, 0, 0>(p, stream);
   }
@@ -250,6 +256,6 @@ int ddl_launch_conv_patch(ConvParams& p, int mode, hipStream_t stream) {
   p.div_ow = make_fastdiv((unsigned)p.OW);
   p.div_fhw = make_fastdiv((unsigned)(p.FOH * p.FOW));
   p.div_fw = make_fastdiv((unsigned)p.FOW);
-  if (p.OC <= 64) return dispatch_patch<64>(p, mode, stream);
-  return dispatch_patch<128>(p, mode, stream);
+  const int rc = p.OC <= 64 ? dispatch_patch<64>(p, mode, stream) : dispatch_patch<128>(p, mode, stream);
+  return rc;
 }

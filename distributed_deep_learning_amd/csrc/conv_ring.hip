@@ -45,8 +45,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
+// BK = 32 stages are sized for TWO blocks per CU (4 waves per SIMD = 128 VGPRs); every variant fits on its own except
+// the input-BatchNorm one (EPI & 8), which is held to that budget explicitly.
 template <int BN, int BK, int MODE, int EPI>
-__global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(((EPI & 8) != 0 && BK == 32) ? 4 : 1)))
+void conv_ring_kernel(const ConvParams p) {
   constexpr int RP = BK * 2;                // LDS row pitch in bytes
   constexpr int CH = BK / 8;                // 16-byte chunks per row
   constexpr int RW = 1024 / RP;             // rows per LDS-DMA wave-instruction
@@ -218,18 +221,24 @@ __global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
       if constexpr ((EPI & 8) != 0) {
         // 1x1 conv: reduction index == input channel.  This lane's 8 fragment elements are channels cb .. cb+7.
         const int cb = t * BK + ch * 8;
-        const f32x4 s0 = *reinterpret_cast<const f32x4*>(aff + cb), s1 = *reinterpret_cast<const f32x4*>(aff + cb + 4);
-        const f32x4 h0 = *reinterpret_cast<const f32x4*>(aff + icp + cb), h1 = *reinterpret_cast<const f32x4*>(aff + icp + cb + 4);
+        // two passes of 4 channels each: 8 coefficient registers live instead of 16 (the variant must stay under the
+        // 128 VGPRs that keep two blocks on a CU at BK = 32)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) {
-          const u32x4 raw = __builtin_bit_cast(u32x4, b[j]);
-          float f[8];
-          unpack8(raw, f);
-          f[0] = fmaxf(f[0] * s0[0] + h0[0], 0.f); f[1] = fmaxf(f[1] * s0[1] + h0[1], 0.f);
-          f[2] = fmaxf(f[2] * s0[2] + h0[2], 0.f); f[3] = fmaxf(f[3] * s0[3] + h0[3], 0.f);
-          f[4] = fmaxf(f[4] * s1[0] + h1[0], 0.f); f[5] = fmaxf(f[5] * s1[1] + h1[1], 0.f);
-          f[6] = fmaxf(f[6] * s1[2] + h1[2], 0.f); f[7] = fmaxf(f[7] * s1[3] + h1[3], 0.f);
-          b[j] = __builtin_bit_cast(bf16x8, pack8(f));
+        for (int h = 0; h < 2; ++h) {
+          const f32x4 sv = *reinterpret_cast<const f32x4*>(aff + cb + 4 * h);
+          const f32x4 hv = *reinterpret_cast<const f32x4*>(aff + icp + cb + 4 * h);
+#pragma unroll
+          for (int j = 0; j < TM; ++j) {
+            u32x4 raw = __builtin_bit_cast(u32x4, b[j]);
+            const unsigned lo = raw[2 * h], hi = raw[2 * h + 1];
+            const float f0 = fmaxf(__uint_as_float(lo << 16) * sv[0] + hv[0], 0.f);
+            const float f1 = fmaxf(__uint_as_float(lo & 0xffff0000u) * sv[1] + hv[1], 0.f);
+            const float f2 = fmaxf(__uint_as_float(hi << 16) * sv[2] + hv[2], 0.f);
+            const float f3 = fmaxf(__uint_as_float(hi & 0xffff0000u) * sv[3] + hv[3], 0.f);
+            raw[2 * h] = pack_bf16x2(f0, f1);
+            raw[2 * h + 1] = pack_bf16x2(f2, f3);
+            b[j] = __builtin_bit_cast(bf16x8, raw);
+          }
         }
       }
 #pragma unroll
@@ -273,6 +282,10 @@ int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
     }
     if (p.stats != nullptr) {
       if (p.bias != nullptr || p.relu) return -6;               // statistics are taken of the raw conv output
+      if (p.fin.counter != nullptr) {                            // + BatchNorm finalize by the last block of each tile column
+        p.fin_done = 1;
+        return launch_ring<BN, BK, 0, 18>(p, stream);
+      }
       return launch_ring<BN, BK, 0, 2>(p, stream);
     }
     if (p.bias != nullptr || p.relu) return launch_ring<BN, BK, 0, 1>(p, stream);
@@ -312,6 +325,8 @@ int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream) {
   p.div_fhw = make_fastdiv((unsigned)(p.FOH * p.FOW));
   p.div_fw = make_fastdiv((unsigned)p.FOW);
   const int bk = ring_bk(p);
-  if (p.OC <= 64) return bk == 32 ? dispatch_ring<64, 32>(p, mode, stream) : dispatch_ring<64, 64>(p, mode, stream);
-  return bk == 32 ? dispatch_ring<128, 32>(p, mode, stream) : dispatch_ring<128, 64>(p, mode, stream);
+  int rc;
+  if (p.OC <= 64) rc = bk == 32 ? dispatch_ring<64, 32>(p, mode, stream) : dispatch_ring<64, 64>(p, mode, stream);
+  else            rc = bk == 32 ? dispatch_ring<128, 32>(p, mode, stream) : dispatch_ring<128, 64>(p, mode, stream);
+  return rc;
 }

@@ -354,3 +354,34 @@ extern "C" int ddl_spin(long long microseconds, void* stream) {
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, microseconds * 100, 1 << 22, (int*)nullptr);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------- channel windows of NHWC buffers
+// dst[row][0..C) = src[row][0..C) for two [M][*] bf16 buffers with independent row pitches (elements): packs a dense
+// tensor into a channel window of a wider buffer (dense-block feature map) or extracts a window into a dense tensor.
+// One 16-byte chunk per thread step; base pointers already point at the window's first channel.
+__global__ __launch_bounds__(256) void copy_channels_kernel(const bf16_t* __restrict__ src, long long src_ld,
+                                                            bf16_t* __restrict__ dst, long long dst_ld, long long M,
+                                                            FastDiv div_c8) {
+  const long long total = M * (long long)div_c8.d;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    long long row;
+    int ch;
+    if (total < (1ll << 31)) {
+      row = (long long)fastdiv((unsigned)i, div_c8);
+      ch = (int)(i - row * (long long)div_c8.d);
+    } else {
+      row = i / (long long)div_c8.d;
+      ch = (int)(i % (long long)div_c8.d);
+    }
+    *reinterpret_cast<u32x4*>(dst + row * dst_ld + ch * 8) =
+        *reinterpret_cast<const u32x4*>(src + row * src_ld + ch * 8);
+  }
+}
+
+extern "C" int ddl_copy_channels(const void* src, int src_ld, void* dst, int dst_ld, long long M, int C, void* stream) {
+  if (C <= 0 || C % 8 != 0 || M <= 0 || src_ld < C || dst_ld < C || src_ld % 8 != 0 || dst_ld % 8 != 0) return -1;
+  if ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) return -2;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(grid_for(M * (C / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, (long long)src_ld, (bf16_t*)dst, (long long)dst_ld, M, make_fastdiv((unsigned)(C / 8)));
+  return (int)hipGetLastError();
+}

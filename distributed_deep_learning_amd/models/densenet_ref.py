@@ -9,7 +9,9 @@ in 32 tensors at the defaults), with the reference's defects fixed (SURVEY Appen
 * emits **logits** (A5: the reference applies Softmax and then CrossEntropyLoss),
 * global average pool instead of ``AvgPool2d(7)`` on an 8x8 map (A10),
 * BN momentum is exposed, PyTorch default 0.1 (A7: reference uses 0.99; pass ``bn_momentum=0.99`` for parity),
-* pre-activation BN+ReLU run as one fused kernel on the concatenated features.
+* pre-activation BN+ReLU run as one fused kernel reading the block's single feature buffer in place: the features
+  are never concatenated on the GPU (``model.py:43-47`` re-copies them for every layer), conv2's epilogue writes its
+  growth channels into the buffer and supplies their batch statistics to every later layer.
 """
 from __future__ import annotations
 
@@ -17,7 +19,7 @@ import torch
 import torch.nn as tnn
 
 from .. import nn as dnn
-from ..nn.modules import conv_bn_act, conv_bn_relu_pool, to_device_input
+from ..nn.modules import conv_bn_act, conv_bn_relu_pool, dense_block
 
 
 class DenseLayer(tnn.Module):
@@ -28,11 +30,9 @@ class DenseLayer(tnn.Module):
         self.norm2 = dnn.BatchNorm2d(bn_size * growth, eps=eps, momentum=momentum)
         self.conv2 = dnn.Conv2d(bn_size * growth, growth, 3, 1, 1, bias=False)
 
-    def forward(self, features):
-        x = torch.cat(features, 1) if len(features) > 1 else features[0]
-        x = self.norm1(x, relu=True)
-        x = conv_bn_act(self.conv1, self.norm2, x, relu=True)     # conv1x1 -> BN -> ReLU fused
-        return self.conv2(x)
+    def forward(self, x):
+        """The layer alone: ``x`` = every earlier feature map; returns ``x`` extended by this layer's channels."""
+        return dense_block([(self.norm1, self.conv1, self.norm2, self.conv2)], x)
 
 
 class DenseBlock(tnn.Module):
@@ -42,10 +42,8 @@ class DenseBlock(tnn.Module):
                                      for i in range(num_layers))
 
     def forward(self, x):
-        feats = [x]
-        for layer in self.layers:
-            feats.append(layer(feats))
-        return torch.cat(feats, 1)
+        # GPU: one feature buffer, every layer writes its growth channels in place (nn.functional.DenseBlock)
+        return dense_block([(l.norm1, l.conv1, l.norm2, l.conv2) for l in self.layers], x)
 
 
 class Transition(tnn.Module):

@@ -98,9 +98,8 @@ class ConvBNAct(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, residual, w_krsc, w_crsk, running_mean, running_var, momentum, eps,
                 stride, pad, relu, cin_real, slabs):
         x = K.nhwc(_bf16(x))
-        y_conv, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True, slab=slabs[0] if slabs else None)
-        N, _, P, Q = y_conv.shape
-        vec = K.bn_finalize(stats, N * P * Q, gamma, beta, running_mean, running_var, momentum, eps)
+        y_conv, vec = K.conv2d_fwd_bn(x, w_krsc, stride, pad, gamma, beta, running_mean, running_var, momentum, eps,
+                                      slabs[0] if slabs else K.new_slab(w_krsc.shape[0], x.device))
         res = K.nhwc(_bf16(residual)) if residual is not None else None
         out, mask = K.bn_apply(y_conv, vec[2], vec[3], residual=res, relu=relu, want_mask=True)
         ctx.save_for_backward(x, y_conv, mask, vec, gamma, w_crsk)
@@ -132,9 +131,8 @@ class ConvBNReluPool(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, w_krsc, w_crsk, running_mean, running_var, momentum, eps, stride, pad,
                 cin_real, slabs, pool):
         x = K.nhwc(_bf16(x))
-        y_conv, stats = K.conv2d_fwd(x, w_krsc, stride, pad, want_stats=True, slab=slabs[0] if slabs else None)
-        N, _, P, Q = y_conv.shape
-        vec = K.bn_finalize(stats, N * P * Q, gamma, beta, running_mean, running_var, momentum, eps)
+        y_conv, vec = K.conv2d_fwd_bn(x, w_krsc, stride, pad, gamma, beta, running_mean, running_var, momentum, eps,
+                                      slabs[0] if slabs else K.new_slab(w_krsc.shape[0], x.device))
         rows = K.vec_rows(vec)
         out, idx = K.bn_relu_maxpool_fwd(y_conv, rows[2], rows[3], *pool)
         ctx.save_for_backward(x, y_conv, idx, vec, gamma, w_crsk)
@@ -183,10 +181,8 @@ class ResidualBlock(torch.autograd.Function):
             krsc, crsk = conv.packed()
             slabs = bn.slabs(inp.device)
             bn._count_batch()
-            y_conv, stats = K.conv2d_fwd(inp, krsc, conv.stride[0], conv.padding[0], want_stats=True, slab=slabs[0])
-            n, _, p_, q_ = y_conv.shape
-            vec = K.bn_finalize(stats, n * p_ * q_, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                bn._momentum(), bn.eps)
+            y_conv, vec = K.conv2d_fwd_bn(inp, krsc, conv.stride[0], conv.padding[0], bn.weight, bn.bias, bn.running_mean,
+                                          bn.running_var, bn._momentum(), bn.eps, slabs[0])
             rows = K.vec_rows(vec)
             out = mask = None
             if apply:
@@ -310,6 +306,127 @@ class ResidualBlock(torch.autograd.Function):
             out.extend(grads[idx])
         # parameter order given to apply(): ds first (if any), then the main units — same as metas
         return (dx, None, None, *out)
+
+
+def _aux_slab(mod, channels, device):
+    """A persistent self-cleaning statistics slab hung on a module that has no BatchNorm of its own."""
+    slab = getattr(mod, "_ddl_aux_slab", None)
+    if slab is None or slab.device != device or slab.shape[-1] != channels:
+        slab = K.new_slab(channels, device)
+        mod._ddl_aux_slab = slab
+    return slab
+
+
+class DenseBlock(torch.autograd.Function):
+    """A whole DenseNet block as ONE autograd node working on ONE feature buffer ``[N, c0 + L*growth, H, W]``.
+
+    The reference concatenates all earlier feature maps again for every layer
+    (``/root/reference/src/pytorch/CNN/model.py:43-47,75-83``): O(L^2) copies forward, O(L^2) slice-adds backward.
+    Here every layer is  BN1+ReLU (reads the buffer's channel prefix in place) -> conv1x1 -> BN2+ReLU -> conv3x3 whose
+    epilogue writes the ``growth`` new channels straight into their window of the buffer.  Batch statistics of a
+    channel are taken once, by the conv that produced it, and shared by every later BN1 through a per-block totals
+    table (``csrc/bn.hip``).  Backward walks the layers in reverse over one gradient buffer: BN1's input gradient is
+    accumulated into the prefix window, conv2's output gradient is the layer's own window.
+    ``layers`` = ``[(norm1, conv1, norm2, conv2), ...]``; ``params`` = their parameters, six per layer."""
+
+    @staticmethod
+    def forward(ctx, x, layers, *params):
+        x = K.nhwc(_bf16(x))
+        N, c0, H, W = x.shape
+        growth = [l[3].out_channels for l in layers]
+        ctot = c0 + sum(growth)
+        dev = x.device
+        buf = torch.empty((N, ctot, H, W), dtype=BF16, device=dev, memory_format=torch.channels_last)
+        tot = K.new_totals(ctot, dev)
+        M = N * H * W
+        K.copy_channels(x, K.ChannelWindow(buf, 0, c0))
+        first = layers[0][0]
+        K.slab_fold_totals(K.bn_stats(x, slab=first.slabs(dev)[0]), c0, tot, 0)
+        saved, cin = [], c0
+        for (n1, c1, n2, c2), g in zip(layers, growth):
+            n1._count_batch()
+            vec1 = K.bn_finalize_totals(tot, cin, M, n1.weight, n1.bias, n1.running_mean, n1.running_var, n1._momentum(),
+                                        n1.eps)
+            r1 = K.vec_rows(vec1)
+            a1, m1 = K.bn_apply_window(K.ChannelWindow(buf, 0, cin), r1[2], r1[3], relu=True)
+            k1, t1 = c1.packed()
+            n2._count_batch()
+            z1, vec2 = K.conv2d_fwd_bn(a1, k1, c1.stride[0], c1.padding[0], n2.weight, n2.bias, n2.running_mean,
+                                       n2.running_var, n2._momentum(), n2.eps, n2.slabs(dev)[0])
+            r2 = K.vec_rows(vec2)
+            a2, m2 = K.bn_apply(z1, r2[2], r2[3], relu=True, want_mask=True)
+            k2, t2 = c2.packed()
+            st2 = K.conv2d_fwd_into(a2, k2, K.ChannelWindow(buf, cin, g), c2.stride[0], c2.padding[0],
+                                    slab=_aux_slab(c2, g, dev))
+            K.slab_fold_totals(st2, g, tot, cin)
+            saved.extend([a1, m1, vec1, t1, z1, a2, m2, vec2, t2])
+            cin += g
+        ctx.save_for_backward(buf, *saved)
+        ctx.layers, ctx.c0, ctx.growth = layers, c0, growth
+        return buf
+
+    @staticmethod
+    def backward(ctx, dout):
+        buf, *saved = ctx.saved_tensors
+        layers, c0, growth = ctx.layers, ctx.c0, ctx.growth
+        N, ctot, H, W = buf.shape
+        # ONE gradient buffer for the block.  The upstream gradient is never modified: the last layer (first visited)
+        # writes  dout[prefix] + its BN1 gradient  into the new buffer, every earlier layer accumulates in place.
+        dout = K.nhwc(_bf16(dout))
+        gbuf = torch.empty_like(dout, memory_format=torch.channels_last)
+        src = dout
+        grads = [None] * (6 * len(layers))
+        cin = ctot
+        for li in range(len(layers) - 1, -1, -1):
+            n1, c1, n2, c2 = layers[li]
+            g = growth[li]
+            cin -= g
+            a1, m1, vec1, t1, z1, a2, m2, vec2, t2 = saved[9 * li:9 * li + 9]
+            r1, r2 = K.vec_rows(vec1), K.vec_rows(vec2)
+            dy2 = torch.empty((N, g, H, W), dtype=BF16, device=buf.device, memory_format=torch.channels_last)
+            K.copy_channels(K.ChannelWindow(src, cin, g), dy2)
+            da2 = K.conv2d_dgrad(dy2, t2, (H, W), c2.stride[0], c2.padding[0])
+            dw2 = _wgrad(c2.weight, dy2, a2, *c2.kernel_size, c2.stride[0], c2.padding[0], c2.in_channels)
+            dz1, _, dg2, db2 = _bn_bwd(da2, m2, z1, n2.weight, n2.bias, n2.weight, r2[0], r2[1], True, False,
+                                       n2.slabs(buf.device)[1])
+            da1 = K.conv2d_dgrad(dz1, t1, (H, W), c1.stride[0], c1.padding[0])
+            dw1 = _wgrad(c1.weight, dz1, a1, *c1.kernel_size, c1.stride[0], c1.padding[0], c1.in_channels)
+            arena, gout = _bn_grad_out(n1.weight, n1.bias)
+            dg1, db1 = K.bn_backward_window(da1, m1, K.ChannelWindow(buf, 0, cin), n1.weight, r1[0], r1[1],
+                                            K.ChannelWindow(gbuf, 0, cin), add_to=K.ChannelWindow(src, 0, cin),
+                                            relu=True, slab=n1.slabs(buf.device)[1], grad_out=gout)
+            src = gbuf
+            if arena is not None:
+                arena.notify_grad_ready(n1.weight)
+                arena.notify_grad_ready(n1.bias)
+                dg1 = db1 = None
+            grads[6 * li:6 * li + 6] = [dg1, db1, dw1, dg2, db2, dw2]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, c0, H, W), dtype=BF16, device=buf.device, memory_format=torch.channels_last)
+            K.copy_channels(K.ChannelWindow(gbuf, 0, c0), dx)
+        return (dx, None, *grads)
+
+
+def dense_block_eval(x, layers):
+    """Inference forward of a dense block on the same single buffer (running statistics, nothing saved)."""
+    x = K.nhwc(_bf16(x))
+    N, c0, H, W = x.shape
+    growth = [l[3].out_channels for l in layers]
+    buf = torch.empty((N, c0 + sum(growth), H, W), dtype=BF16, device=x.device,
+                      memory_format=torch.channels_last)
+    K.copy_channels(x, K.ChannelWindow(buf, 0, c0))
+    cin = c0
+    for (n1, c1, n2, c2), g in zip(layers, growth):
+        s1, h1 = n1._eval_affine()
+        a1, _ = K.bn_apply_window(K.ChannelWindow(buf, 0, cin), s1, h1, relu=True, want_mask=False)
+        z1, _ = K.conv2d_fwd(a1, c1.packed()[0], c1.stride[0], c1.padding[0])
+        s2, h2 = n2._eval_affine()
+        a2 = K.bn_apply(z1, s2, h2, relu=True)
+        K.conv2d_fwd_into(a2, c2.packed()[0], K.ChannelWindow(buf, cin, g), c2.stride[0], c2.padding[0],
+                          want_stats=False)
+        cin += g
+    return buf
 
 
 class ConvBiasAct(torch.autograd.Function):

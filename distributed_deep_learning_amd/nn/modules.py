@@ -287,6 +287,35 @@ def residual_block(units, ds, x):
     return h
 
 
+_DENSE_BUFFER = os.environ.get("DDL_DENSE_BUFFER", "1") != "0"      # 0: concatenate layer by layer (A/B, debugging)
+
+
+def dense_block(layers, x):
+    """Run a DenseNet block — ``layers``: ``(norm1, conv1, norm2, conv2)`` per bottleneck layer, each computing
+    ``conv2(relu(norm2(conv1(relu(norm1(concat of everything before))))))`` — and return the concatenation of the
+    input and every layer's output.  On the GPU the block lives in ONE feature buffer that the layers read and extend
+    in place (:class:`functional.DenseBlock`); elsewhere the features are concatenated layer by layer."""
+    mods_ok = all(c.bias is None and c._native_ok() and c.in_channels % 8 == 0 and c.out_channels % 8 == 0
+                  and b.affine and b.track_running_stats
+                  for n1, c1, n2, c2 in layers for c, b in ((c1, n1), (c2, n2)))
+    if x.is_cuda and mods_ok and x.shape[1] % 8 == 0 and layers and _DENSE_BUFFER:
+        training = all(b.training for n1, _, n2, _ in layers for b in (n1, n2))
+        if training and torch.is_grad_enabled():
+            params = []
+            for n1, c1, n2, c2 in layers:
+                params += [n1.weight, n1.bias, c1.weight, n2.weight, n2.bias, c2.weight]
+            return F.DenseBlock.apply(x, tuple(layers), *params)
+        if not torch.is_grad_enabled() and not any(b.training for n1, _, n2, _ in layers for b in (n1, n2)):
+            return F.dense_block_eval(x, layers)
+    feats = [x]
+    for n1, c1, n2, c2 in layers:
+        h = torch.cat(feats, 1) if len(feats) > 1 else feats[0]
+        h = n1(h, relu=True)
+        h = conv_bn_act(c1, n2, h, relu=True)
+        feats.append(c2(h))
+    return torch.cat(feats, 1)
+
+
 class ReLU(tnn.Module):
     def __init__(self, inplace: bool = False):
         super().__init__()

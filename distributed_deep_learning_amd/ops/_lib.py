@@ -31,6 +31,14 @@ _SIGS = {
     "ddl_bn_slots": [],
     "ddl_slab_fold": [_vp, _i, _vp, _i, _vp],
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
+    "ddl_bn_stats_ld": [_vp, _i, _vp, _i, _i, _vp],
+    "ddl_bn_apply_ld": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_bn_backward_ld": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "ddl_slab_fold_totals": [_vp, _i, _vp, _i, _i, _vp],
+    "ddl_bn_finalize_totals": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "ddl_copy_channels": [_vp, _i, _vp, _i, _ll, _i, _vp],
+    "ddl_conv_fwd_bn": [_vp, _vp, _vp, _i, _vp] + [_i] * 11 + [_vp, _vp, _vp, _vp, _f, _f, _vp, _vp],
+    "ddl_conv_fwd_ld": [_vp, _vp, _vp, _i, _vp] + [_i] * 11 + [_vp],
     "ddl_bn_finalize": [_vp, _i, _i, _f, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _i, _i, _vp],

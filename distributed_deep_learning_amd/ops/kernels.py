@@ -98,6 +98,29 @@ def conv2d_fwd(x, w_krsc, stride=1, pad=0, bias=None, relu=False, want_stats=Fal
     return y, stats
 
 
+def conv2d_fwd_bn(x, w_krsc, stride, pad, gamma, beta, running_mean, running_var, momentum, eps, slab):
+    """``conv2d_fwd(want_stats=True)`` + :func:`bn_finalize` as ONE launch: the last block of every output-channel
+    tile folds the statistics slab and writes ``vec[4, K]`` = (mean, invstd, scale, shift), running statistics included
+    (``csrc/conv_epilogue.h``, last-arriver hand-off; kernels without it get the finalize launched behind them by the
+    library).  ``slab``: this layer's zeroed :func:`new_slab` workspace (left zero).  Returns ``(y, vec)``."""
+    lib = _lib.require()
+    _chk_act(x, "conv2d_fwd_bn")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    K, R, S, C2 = w_krsc.shape
+    if C2 != Cc:
+        raise ValueError(f"conv2d_fwd_bn: input has {Cc} channels, filter expects {C2}")
+    if w_krsc.dtype != BF16 or not w_krsc.is_contiguous():
+        raise ValueError("conv2d_fwd_bn: filter must be a contiguous bf16 [K,R,S,C] tensor")
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    y = torch.empty((N, K, P, Q), dtype=BF16, device=x.device, memory_format=CL)
+    vec = torch.empty((4, K), dtype=torch.float32, device=x.device)
+    check(lib.ddl_conv_fwd_bn(ptr(x), ptr(w_krsc), ptr(y), 0, ptr(slab), N, P, Q, H, W, Cc, K, R, S, stride, pad, ptr(gamma),
+                              ptr(beta), ptr(running_mean), ptr(running_var), float(momentum), float(eps), ptr(vec),
+                              stream_ptr()), "conv2d_fwd_bn")
+    return y, vec
+
+
 def conv1x1_fwd_inbn(z, w_krsc, in_scale, in_shift, slab=None):
     """``conv1x1(relu(z * in_scale + in_shift), w)`` with the producer's BatchNorm + ReLU applied to the input
     fragments INSIDE the kernel (``csrc/conv_ring.hip``, EPI bit 8): ``z`` is a raw conv output, the normalised
@@ -114,6 +137,141 @@ def conv1x1_fwd_inbn(z, w_krsc, in_scale, in_shift, slab=None):
     check(lib.ddl_conv_fwd_inbn(ptr(z), ptr(w_krsc), ptr(y), ptr(stats), ptr(in_scale), ptr(in_shift), N, H, W, Cc, K,
                                 stream_ptr()), "conv1x1_fwd_inbn")
     return y, stats
+
+
+# ------------------------------------------------------------------------------- channel windows (dense blocks)
+class ChannelWindow:
+    """Channels ``[c0, c0 + c)`` of a bf16 NHWC buffer ``[N, Ctot, H, W]`` (channels_last) — what a dense block's
+    layers read and write instead of concatenated copies (``/root/reference/src/pytorch/CNN/model.py:43-47`` re-copies
+    every earlier feature map for every layer).  Only an address and a row pitch: no tensor view is created."""
+    __slots__ = ("buf", "c0", "c", "ld", "rows", "shape")
+
+    def __init__(self, buf: torch.Tensor, c0: int, c: int):
+        _chk_act(buf, "ChannelWindow")
+        N, Ctot, H, W = buf.shape
+        if not buf.is_contiguous(memory_format=CL):
+            raise ValueError("ChannelWindow: the buffer must be channels_last contiguous")
+        if c0 % 8 or c % 8 or Ctot % 8 or c0 < 0 or c <= 0 or c0 + c > Ctot:
+            raise ValueError(f"ChannelWindow: window [{c0}, {c0 + c}) of {Ctot} channels must be 8-aligned and in range")
+        self.buf, self.c0, self.c, self.ld, self.rows, self.shape = buf, c0, c, Ctot, N * H * W, (N, c, H, W)
+
+    def ptr(self) -> int:
+        return self.buf.data_ptr() + 2 * self.c0
+
+
+def copy_channels(src, dst):
+    """``dst <- src`` where each side is a dense bf16 NHWC tensor or a :class:`ChannelWindow` of the same shape."""
+    lib = _lib.require()
+
+    def side(t):
+        if isinstance(t, ChannelWindow):
+            return t.ptr(), t.ld, t.shape
+        _chk_act(t, "copy_channels")
+        if not t.is_contiguous(memory_format=CL):
+            raise ValueError("copy_channels: dense operands must be channels_last contiguous")
+        return t.data_ptr(), t.shape[1], tuple(t.shape)
+
+    sp, sld, ss = side(src)
+    dp, dld, ds = side(dst)
+    if ss != ds:
+        raise ValueError(f"copy_channels: shapes differ, {ss} vs {ds}")
+    check(lib.ddl_copy_channels(sp, sld, dp, dld, ss[0] * ss[2] * ss[3], ss[1], stream_ptr()), "copy_channels")
+    return dst
+
+
+def conv2d_fwd_into(x, w_krsc, window: ChannelWindow, stride=1, pad=0, slab=None, want_stats=True):
+    """Forward convolution whose result lands in ``window`` (a channel window of a wider buffer) straight from the
+    kernel's epilogue; with ``want_stats`` the statistics of the new channels go to ``slab``.  Returns the slab."""
+    lib = _lib.require()
+    _chk_act(x, "conv2d_fwd_into")
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    K, R, S, C2 = w_krsc.shape
+    P, Q = conv_out_size(H, R, stride, pad), conv_out_size(W, S, stride, pad)
+    if C2 != Cc or w_krsc.dtype != BF16 or not w_krsc.is_contiguous():
+        raise ValueError("conv2d_fwd_into: needs a contiguous bf16 [K,R,S,C] filter matching the input channels")
+    if window.shape != (N, K, P, Q):
+        raise ValueError(f"conv2d_fwd_into: window {window.shape} is not the conv output {(N, K, P, Q)}")
+    stats = (slab if slab is not None else new_slab(K, x.device)) if want_stats else None
+    check(lib.ddl_conv_fwd_ld(ptr(x), ptr(w_krsc), window.ptr(), window.ld, ptr(stats), N, P, Q, H, W, Cc, K, R, S, stride,
+                              pad, stream_ptr()), "conv2d_fwd_into")
+    return stats
+
+
+def bn_stats_window(win: ChannelWindow, slab=None):
+    lib = _lib.require()
+    if slab is None:
+        slab = new_slab(win.c, win.buf.device)
+    check(lib.ddl_bn_stats_ld(win.ptr(), win.ld, ptr(slab), win.rows, win.c, stream_ptr()), "bn_stats_window")
+    return slab
+
+
+def new_totals(channels: int, device) -> torch.Tensor:
+    """Per-block statistics table ``[2, Ctot]`` fp64 (sum, sum of squares per channel of a dense block's buffer)."""
+    return torch.empty((2, channels), dtype=torch.float64, device=device)
+
+
+def slab_fold_totals(slab, channels: int, totals, c0: int):
+    """Fold a statistics slab of ``channels`` channels (conv epilogue / :func:`bn_stats_window`) into columns
+    ``[c0, c0 + channels)`` of ``totals``; the slab is zero afterwards."""
+    lib = _lib.require()
+    check(lib.ddl_slab_fold_totals(ptr(slab), channels, ptr(totals), totals.shape[1], c0, stream_ptr()), "slab_fold_totals")
+
+
+def bn_finalize_totals(totals, channels: int, count, gamma, beta, running_mean, running_var, momentum, eps):
+    """:func:`bn_finalize` for the first ``channels`` channels of a block's totals table (which stays intact)."""
+    lib = _lib.require()
+    vec = torch.empty((4, channels), dtype=torch.float32, device=totals.device)
+    v0, row = vec.data_ptr(), 4 * channels
+    check(lib.ddl_bn_finalize_totals(ptr(totals), totals.shape[1], channels, float(count), ptr(gamma), ptr(beta),
+                                     ptr(running_mean), ptr(running_var), float(momentum), float(eps), v0, v0 + row,
+                                     v0 + 2 * row, v0 + 3 * row, stream_ptr()), "bn_finalize_totals")
+    return vec
+
+
+def bn_apply_window(win: ChannelWindow, scale, shift, relu=True, want_mask=True):
+    """Dense ``y = act(win * scale + shift)`` plus (``want_mask``) the ReLU bit mask, reading the window in place."""
+    lib = _lib.require()
+    N, Cc, H, W = win.shape
+    y = torch.empty((N, Cc, H, W), dtype=BF16, device=win.buf.device, memory_format=CL)
+    mask = torch.empty((win.rows, Cc // 8), dtype=torch.uint8, device=win.buf.device) if (relu and want_mask) else None
+    check(lib.ddl_bn_apply_ld(win.ptr(), win.ld, ptr(y), ptr(mask), ptr(scale), ptr(shift), win.rows, Cc, int(relu),
+                              stream_ptr()), "bn_apply_window")
+    return y, mask
+
+
+def bn_backward_window(dy, mask, xwin: ChannelWindow, gamma, mean, invstd, dxwin: ChannelWindow, add_to=None,
+                       relu=True, slab=None, grad_out=None):
+    """BatchNorm backward whose input was ``xwin``; the input gradient goes to ``dxwin``.  ``add_to`` (a window of the
+    same position and pitch, possibly ``dxwin`` itself): ``dxwin = add_to + gradient``.  ``grad_out = (dgamma, dbeta)``
+    fp32 tensors to accumulate into, else fresh ones are returned."""
+    lib = _lib.require()
+    _chk_act(dy, "bn_backward_window")
+    dy = nhwc(dy)
+    Cc = xwin.c
+    if tuple(dy.shape) != xwin.shape or dxwin.shape != xwin.shape:
+        raise ValueError("bn_backward_window: dy / x window / dx window shapes differ")
+    if add_to is not None and (add_to.shape != dxwin.shape or add_to.ld != dxwin.ld or add_to.c0 != dxwin.c0):
+        raise ValueError("bn_backward_window: add_to must be the same window of a buffer with the same pitch")
+    if relu and (mask is None or mask.numel() != xwin.rows * Cc // 8):
+        raise ValueError("bn_backward_window: relu=True needs the mask of bn_apply_window")
+    if grad_out is not None:
+        dg, db = grad_out
+        if not (dg.is_contiguous() and db.is_contiguous() and dg.numel() == Cc and db.numel() == Cc
+                and dg.dtype == torch.float32 and db.dtype == torch.float32):
+            raise ValueError("bn_backward_window: grad_out must be two contiguous fp32 [C] tensors")
+    else:
+        t = torch.empty((2, Cc), dtype=torch.float32, device=dy.device)
+        dg, db = t[0], t[1]
+    if slab is None:
+        slab = new_slab(Cc, dy.device)
+    coef = _slab_scratch(slab, Cc)
+    check(lib.ddl_bn_backward_ld(ptr(dy), ptr(mask) if relu else None, xwin.ptr(), xwin.ld, ptr(gamma), ptr(mean),
+                                 ptr(invstd), dxwin.ptr(), dxwin.ld, add_to.ptr() if add_to is not None else None,
+                                 ptr(dg), ptr(db), ptr(slab),
+                                 ptr(coef), xwin.rows, Cc, int(relu), int(grad_out is not None), stream_ptr()),
+          "bn_backward_window")
+    return dg, db
 
 
 def dgrad_bn_sums_ok(dy, w_crsk, stride, R, S) -> bool:
