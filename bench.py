@@ -193,6 +193,8 @@ def run_rank(a) -> int:
 
     for _ in range(a.warmup):
         loss = step()
+    from distributed_deep_learning_amd.utils.host import freeze_gc
+    freeze_gc()           # a full Python GC pass over ~270k live objects costs 70-115 ms of host time (utils/host.py)
     fence()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]     # per-step GPU time (diagnostics only)
     ms0 = torch.cuda.memory_stats(dev)

@@ -21,7 +21,8 @@ model = models.build(name).to(dev)
 arena = ParamArena(model.named_parameters())
 opt = FusedSGD(arena, lr=0.01, momentum=0.9)
 crit = SoftmaxCrossEntropyLoss()
-shapes = {"resnet50": ((3, 224, 224), 1000), "cnn": ((3, 64, 64), 6), "mlp": ((48,), 5), "lenet5": ((1, 28, 28), 10)}
+shapes = {"resnet50": ((3, 224, 224), 1000), "cnn": ((3, 64, 64), 6), "mlp": ((48,), 5), "lenet5": ((1, 28, 28), 10),
+          "resnet18_cifar": ((3, 32, 32), 10)}
 shape, classes = shapes[name]
 x = torch.randn(B, *shape, device=dev)
 y = torch.randint(0, classes, (B,), device=dev)
@@ -33,9 +34,18 @@ def step():
     opt.step()
 
 
+import time  # noqa: E402
+
 for _ in range(5):
     step()
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f"20 steps: host enqueue {(t1 - t0) / 20 * 1e3:.3f} ms/step, wall {(t2 - t0) / 20 * 1e3:.3f} ms/step", flush=True)
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(10):

@@ -88,14 +88,19 @@ def stock_mlp():
 
 # ------------------------------------------------------------------------------------------ harness
 def timeit(fn, steps):
+    import gc
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.freeze()             # same for ours and stock: no full-GC pause (70-115 ms) inside a timed loop of 1-10 ms steps
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    gc.unfreeze()
+    return dt
 
 
 def workload(name, B):

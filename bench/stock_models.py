@@ -98,6 +98,9 @@ if __name__ == "__main__":
         print("[stock] warm step", i, flush=True)
     done.set()
     torch.cuda.synchronize()
+    import gc
+    gc.collect()
+    gc.freeze()             # as bench.py does for ours (utils/host.py): no full-GC pause inside the timed loop
     t0 = time.time()
     for _ in range(steps):
         loss = step()

@@ -308,6 +308,14 @@ class Trainer:
 
     def fit(self) -> List[dict]:
         cfg = self.cfg
+        from .utils.host import freeze_gc, unfreeze_gc
+        freeze_gc()             # model, arena and loaders exist: keep full GC passes off the launch-bound step loop
+        try:
+            return self._fit(cfg)
+        finally:
+            unfreeze_gc()
+
+    def _fit(self, cfg) -> List[dict]:
         for epoch in range(self.epoch + 1, cfg.epochs + 1):
             self.train_loader.set_epoch(epoch)
             if self.verbose:
