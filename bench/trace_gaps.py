@@ -3,7 +3,10 @@
 idle time on the main queue, and what the tiny BatchNorm finalize kernels cost end to end (previous kernel's end ->
 next kernel's start on the same queue).
 
-    python bench/trace_gaps.py gpurun_out/<dir>/**/*_kernel_trace.csv [top_n]
+    python bench/trace_gaps.py gpurun_out/<dir>/**/*_kernel_trace.csv [top_n] [list]
+
+With ``list`` every launch of the last step is printed in start order (offset into the step, duration, queue, grid,
+workgroup, LDS bytes, name) — the per-layer view of the real step rather than of an isolated layer loop.
 """
 import collections
 import csv
@@ -35,6 +38,14 @@ def main():
     m = [r for r in step if r["Queue_Id"] == mainq]
     idle = sum(max(0, int(b["Start_Timestamp"]) - int(a["End_Timestamp"])) for a, b in zip(m, m[1:])) / 1e6
     print(f"queues {dict(queues)}; main queue {mainq}: {len(m)} kernels, idle between kernels {idle:.3f} ms")
+    if len(sys.argv) > 3 and sys.argv[3] == "list":
+        t0 = int(step[0]["Start_Timestamp"])
+        for r in step:
+            n = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            n = n.split("(")[0][:60]
+            s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+            print(f"    +{(s_ - t0) / 1e6:8.3f} {(e_ - s_) / 1e6:7.3f} ms q{r['Queue_Id']} grid {r.get('Grid_Size_X', '?'):>8} "
+                  f"wg {r.get('Workgroup_Size_X', '?'):>4} lds {r.get('LDS_Block_Size', '?'):>6} {n}")
     for key in ("bn_bwd_finalize", "bn_finalize"):
         tot = n = 0
         for i in range(1, len(m) - 1):
