@@ -62,6 +62,10 @@ struct ConvParams {
 bool ddl_conv_ring_supported(const ConvParams& p);
 int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream);
 
+// conv_pring.hip (persistent ring kernel with an asynchronous wave-private epilogue: wide outputs, many tiles)
+bool ddl_conv_pring_supported(const ConvParams& p);
+int ddl_launch_conv_pring(ConvParams& p, int mode, hipStream_t stream);
+
 // conv_patch.hip (3x3 / stride 1 / pad 1 with an LDS-resident input patch)
 bool ddl_conv_patch_supported(const ConvParams& p);
 int ddl_launch_conv_patch(ConvParams& p, int mode, hipStream_t stream);

@@ -97,6 +97,31 @@ def _stream(index: int) -> torch.cuda.Stream:
     return s
 
 
+def pick_stream(device: torch.device, beside=(), tries: int = 8) -> torch.cuda.Stream:
+    """A new normal-priority stream that was MEASURED to run concurrently with the current stream and with every stream
+    in ``beside`` (the communicator's stream: a collective that shares a hardware queue with the compute stream or with
+    the wgrad side stream serialises with it instead of overlapping backward).  Falls back to the last candidate when
+    no candidate passes (or while a capture is in progress / the calibration kernel cannot be launched)."""
+    main = torch.cuda.current_stream(device)
+    cand = None
+    for _ in range(max(1, tries)):
+        cand = torch.cuda.Stream(device=device, priority=0)
+        try:
+            if torch.cuda.is_current_stream_capturing():
+                break
+            if _overlaps(main, cand) and all(_overlaps(o, cand) for o in beside):
+                break
+        except _lib_error():
+            break
+    return cand
+
+
+def side_stream(device: torch.device) -> torch.cuda.Stream:
+    """The wgrad side stream of ``device`` (created and calibrated on first use)."""
+    with torch.cuda.device(device):
+        return _stream(device.index if device.index is not None else torch.cuda.current_device())
+
+
 def _end_of_backward() -> None:
     global _callback_queued
     _callback_queued = False

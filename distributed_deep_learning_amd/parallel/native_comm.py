@@ -84,7 +84,11 @@ class NativeCommunicator:
         comm = C.c_void_p()
         check(self.lib.ddl_comm_init(C.addressof(ident), rank, world, C.byref(comm)), "ncclCommInitRank")
         self._comm = comm
-        self.stream = torch.cuda.Stream(device=device)
+        # a stream measured to overlap BOTH the compute stream and the wgrad side stream: HIP multiplexes streams onto 4
+        # hardware queues round-robin, and a collective that lands on the compute queue would not overlap backward
+        from ..ops import streams
+        beside = [streams.side_stream(device)] if streams.enabled() else []
+        self.stream = streams.pick_stream(device, beside=beside)
 
     @property
     def version(self) -> int:

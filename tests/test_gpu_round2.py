@@ -196,9 +196,30 @@ def test_default_reducer_transport_is_the_native_communicator():
         assert d.ncomm is not None and d.comm_note is None
         assert d.comm_ranks() == 1 and d.ncomm.user_rank() == 0
         d.ncomm.barrier()
+        # the communicator's stream was picked by measurement: it runs beside the compute stream AND the wgrad side stream
+        from distributed_deep_learning_amd.ops import streams
+        main = torch.cuda.current_stream(_dev())
+        assert d.ncomm.stream.priority == 0
+        assert d.ncomm.stream.cuda_stream != streams.side_stream(_dev()).cuda_stream
+        assert streams._overlaps(main, d.ncomm.stream)                              # noqa: SLF001
+        assert streams._overlaps(streams.side_stream(_dev()), d.ncomm.stream)       # noqa: SLF001
         d.close()
     finally:
         td.destroy_process_group()
+
+
+@pytest.mark.parametrize("env", [{"DDL_CONV_PRING": "2", "DDL_PRING_MIN_TILES": "512"},
+                                 {"DDL_CONV_PRING": "1", "DDL_PRING_MIN_TILES": "512"}, {"DDL_CONV_PRING": "0"}],
+                         ids=["everything-it-can-run", "default-selection", "off"])
+def test_persistent_ring_kernel_matches_fp32(env):
+    """csrc/conv_pring.hip (persistent tiles, wave-private epilogue, stores left in flight behind a counted vmcnt, addend
+    rows requested two rounds ahead, running fp64 statistics per block) against plain fp32 PyTorch: forward + statistics
+    (1x1, 3x3, strided; channel tile changing inside a block's run), plain dgrad, dgrad with a masked and with a plain
+    addend — 500+ tiles, ragged M and OC tails.  The same cases with the kernel switched off pin the comparison."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_pring_child.py")], capture_output=True, text=True,
+                       timeout=600, env=dict(os.environ, **env))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "0 failed" in r.stdout
 
 
 # --------------------------------------------------------------------------------------------- Linear on our GEMM
