@@ -47,7 +47,11 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
 
 // BK = 32 stages are sized for TWO blocks per CU (4 waves per SIMD = 128 VGPRs); every variant fits on its own except
 // the input-BatchNorm one (EPI & 8), which is held to that budget explicitly.
-template <int BN, int BK, int MODE, int EPI>
+// UNI: every K-step lies inside ONE filter tap for all lanes (IC % BK == 0; forward, or dgrad at stride 1).  The tap
+// cursor then lives in scalar registers, each pixel row carries a precomputed byte offset and a bit mask of its in-bounds
+// taps, and a stage's address work shrinks from ~40 vector instructions (six quarter-rate integer multiplies among
+// them, all in front of the MFMA block) to an add, a bit test and a select per LDS-DMA.
+template <int BN, int BK, int MODE, int EPI, bool UNI>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(((EPI & 8) != 0 && BK == 32) ? 4 : 1)))
 void conv_ring_kernel(const ConvParams p) {
   constexpr int RP = BK * 2;                // LDS row pitch in bytes
@@ -114,6 +118,27 @@ void conv_ring_kernel(const ConvParams p) {
     wrow_ok[j] = n < p.OC;
     wrow_off[j] = (unsigned)n * (unsigned)p.KredFull;
   }
+  // UNI: per-row byte offset of tap (0, 0) at this lane's channel chunk, and the bit mask of taps that fall inside the image
+  unsigned xoff[XJ], vmask[XJ];
+  if constexpr (UNI) {
+#pragma unroll
+    for (int j = 0; j < XJ; ++j) {
+      xoff[j] = ((unsigned)(nb[j] + bh[j] * p.IW + bw[j]) * (unsigned)p.IC + (unsigned)(lchunk * 8)) * 2u;
+      unsigned mk = 0u;
+      if (bh[j] > -(1 << 27)) {
+        for (int tr = 0, bit = 0; tr < p.nR; ++tr)
+          for (int ts = 0; ts < p.nS; ++ts, ++bit) {
+            const int r = p.r0 + tr * p.t_step, sx = p.s0 + ts * p.t_step;
+            const int ih = MODE == 0 ? bh[j] + r : bh[j] - r, iw = MODE == 0 ? bw[j] + sx : bw[j] - sx;
+            if ((unsigned)ih < (unsigned)p.IH && (unsigned)iw < (unsigned)p.IW) mk |= 1u << bit;
+          }
+      }
+      vmask[j] = mk;
+    }
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) wrow_off[j] = (wrow_off[j] + (unsigned)(lchunk * 8)) * 2u;
+  }
+  int u_tr = 0, u_ts = 0, u_bit = 0, u_kc = 0;          // UNI: scalar tap cursor
   // reduction cursor of this thread's chunk: (tap row, tap col, channel) inside the tap subset
   int kr, ks_, kc;
   {
@@ -125,6 +150,27 @@ void conv_ring_kernel(const ConvParams p) {
   }
 
   auto issue = [&](int stage) {
+    if constexpr (UNI) {
+      const int r = p.r0 + u_tr * p.t_step, sx = p.s0 + u_ts * p.t_step;
+      const int tap_el = (r * p.IW + sx) * p.IC;
+      const unsigned xdelta = (unsigned)((MODE == 0 ? tap_el : -tap_el) + u_kc) * 2u;
+      const unsigned wdelta = (unsigned)((r * p.S + sx) * p.IC + u_kc) * 2u;
+      char* const sbase = smem + stage * STAGE;
+#pragma unroll
+      for (int j = 0; j < XJ; ++j)
+        lds_dma16(xsrc, sbase + (j * 8 + wid) * 1024, ((vmask[j] >> u_bit) & 1u) ? xoff[j] + xdelta : OOB);
+      if (wwave) {
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+          lds_dma16(wsrc, sbase + XBYTES + (j * 8 + wid) * 1024, wrow_ok[j] ? wrow_off[j] + wdelta : OOB);
+      }
+      u_kc += BK;
+      if (u_kc >= p.IC) {
+        u_kc = 0; ++u_bit;
+        if (++u_ts == p.nS) { u_ts = 0; ++u_tr; }
+      }
+      return;
+    }
     const int r = p.r0 + kr * p.t_step, sx = p.s0 + ks_ * p.t_step;
     const bool kok = kr < p.nR;
     char* const sbase = smem + stage * STAGE;
@@ -259,18 +305,31 @@ void conv_ring_kernel(const ConvParams p) {
   }
 }
 
-template <int BN, int BK, int MODE, int EPI>
-int launch_ring(ConvParams& p, hipStream_t stream) {
+template <int BN, int BK, int MODE, int EPI, bool UNI>
+int launch_ring_u(ConvParams& p, hipStream_t stream) {
   // EPI & 8: room for the [2][IC <= 512, padded to BK] fp32 affine vectors behind the ring (still two blocks per CU at BK=32)
   constexpr int smem = RNS * (RBM + BN) * BK * 2 + ((EPI & 8) ? 2 * 512 * 4 : 0);
   static SmemAttrOnce once;
-  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, BK, MODE, EPI>), smem);
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, BK, MODE, EPI, UNI>), smem);
   if (rc != 0) return rc;
   p.tiles_m = (p.M + RBM - 1) / RBM;
   p.tiles_n = (p.OC + BN - 1) / BN;
   const unsigned grid = (unsigned)p.tiles_m * (unsigned)p.tiles_n;
-  hipLaunchKernelGGL((conv_ring_kernel<BN, BK, MODE, EPI>), dim3(grid), dim3(512), smem, stream, p);
+  hipLaunchKernelGGL((conv_ring_kernel<BN, BK, MODE, EPI, UNI>), dim3(grid), dim3(512), smem, stream, p);
   return (int)hipGetLastError();
+}
+
+// Uniform-tap fast path whenever a K-step never straddles two taps (and never runs past the reduction): IC % BK == 0,
+// forward or stride-1 dgrad, at most 32 taps for the per-row mask.  The input-BatchNorm experiment (EPI & 8) keeps the
+// generic path.  DDL_RING_UNI=0 switches it off (A/B).
+template <int BN, int BK, int MODE, int EPI>
+int launch_ring(ConvParams& p, hipStream_t stream) {
+  static const int uni_on = [] { const char* e = getenv("DDL_RING_UNI"); return e ? atoi(e) : 1; }();
+  if constexpr ((EPI & 8) == 0) {
+    if (uni_on && p.IC % BK == 0 && (MODE == 0 || p.stride == 1) && p.nR * p.nS <= 32)
+      return launch_ring_u<BN, BK, MODE, EPI, true>(p, stream);
+  }
+  return launch_ring_u<BN, BK, MODE, EPI, false>(p, stream);
 }
 
 template <int BN, int BK>
