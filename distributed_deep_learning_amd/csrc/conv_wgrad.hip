@@ -312,22 +312,65 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   const int xc = nn - xs * p.C;
   const unsigned ycol_off = (unsigned)(k0 + ych * 8);
 
-  auto issue = [&](int stage, int mbase) {
+  // ---- load cursor.  Stages are issued strictly in order, 32 pixels apart, so nothing is decoded per stage: byte offsets
+  //      advance by a constant, the row-in-range test is one compare against a scalar, and for "same" convolutions
+  //      (stride 1, output grid == input grid: every 3x3 of ResNet / VGG) the input pixel of tap (r, s) is the output
+  //      pixel plus a constant, with (p, q) carried incrementally (32 = qa * Q + qb: one conditional wrap each).  The
+  //      per-stage decode this replaces was two magic-number divisions and ~8 quarter-rate integer multiplies per DMA,
+  //      about as many issue cycles as the stage's 16 MFMAs.
+  const bool same = !p.plain && p.stride == 1 && p.P == p.H && p.Q == p.W;      // wave-uniform
+  const int qa = BKP / p.Q, qb = BKP - qa * p.Q;
+  const int dr = r - p.pad, ds = xs - p.pad;
+  int mcur = m_begin;
+  unsigned yoff[YJ], xoff[XJ];
+  int ycm[YJ], xcm[XJ], xp[XJ], xq[XJ];
+#pragma unroll
+  for (int j = 0; j < YJ; ++j) {
+    ycm[j] = (j * 4 + wid) * YRW + yrow;
+    yoff[j] = ((unsigned)(m_begin + ycm[j]) * (unsigned)p.K + ycol_off) * 2u;
+  }
+#pragma unroll
+  for (int j = 0; j < XJ; ++j) {
+    xcm[j] = (j * 4 + wid) * XRW + xrow;
+    const int m = m_begin + xcm[j];
+    xp[j] = 0; xq[j] = 0;
+    if (p.plain) {
+      xoff[j] = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
+    } else {
+      const unsigned n = fastdiv((unsigned)m, p.div_pq);
+      const unsigned rem = (unsigned)m - n * p.div_pq.d;
+      xp[j] = (int)fastdiv(rem, p.div_q);
+      xq[j] = (int)rem - xp[j] * (int)p.div_q.d;
+      xoff[j] = ((unsigned)(m + dr * p.W + ds) * (unsigned)p.C + (unsigned)xc) * 2u;
+    }
+  }
+  const unsigned ystep = (unsigned)(BKP * 2) * (unsigned)p.K, xstep = (unsigned)(BKP * 2) * (unsigned)p.C;
+
+  auto issue = [&](int stage) {
     const unsigned sb = smem_addr + (unsigned)(stage * STAGE);
+    const int lim = m_end - mcur;
 #pragma unroll
     for (int j = 0; j < YJ; ++j) {
-      const int m = mbase + (j * 4 + wid) * YRW + yrow;
-      const unsigned off = ((unsigned)m * (unsigned)p.K + ycol_off) * 2u;
-      wg_lds_dma16(ysrc, sb + (unsigned)((j * 4 + wid) * 1024), (ycol_ok && m < m_end) ? off : OOB);
+      wg_lds_dma16(ysrc, sb + (unsigned)((j * 4 + wid) * 1024), (ycol_ok && ycm[j] < lim) ? yoff[j] : OOB);
+      yoff[j] += ystep;
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      const int m = mbase + (j * 4 + wid) * XRW + xrow;
       unsigned off;
-      bool ok = xcol_ok && m < m_end;
+      bool ok = xcol_ok && xcm[j] < lim;
       if (p.plain) {                              // wave-uniform
-        off = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
+        off = xoff[j];
+        xoff[j] += xstep;
+      } else if (same) {                          // wave-uniform
+        const int ih = xp[j] + dr, iw = xq[j] + ds;
+        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        off = xoff[j];
+        xoff[j] += xstep;
+        xq[j] += qb; xp[j] += qa;
+        if (xq[j] >= p.Q) { xq[j] -= p.Q; ++xp[j]; }
+        if (xp[j] >= p.P) xp[j] -= p.P;
       } else {                                    // branch-free: every lane decodes, invalid lanes read out of range
+        const int m = mcur + xcm[j];
         const unsigned n = fastdiv((unsigned)m, p.div_pq);
         const unsigned rem = (unsigned)m - n * p.div_pq.d;
         const unsigned pp = fastdiv(rem, p.div_q);
@@ -339,6 +382,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
       }
       wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + (j * 4 + wid) * 1024), ok ? off : OOB);
     }
+    mcur += BKP;
   };
 
   f32x4 acc[FK][FN];
@@ -353,7 +397,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
 
   // prologue: NS-1 stages in flight (stages past the end are all-zero fills, so the counted waits stay uniform)
 #pragma unroll
-  for (int s = 0; s < NS - 1; ++s) issue(s, m_begin + s * BKP);
+  for (int s = 0; s < NS - 1; ++s) issue(s);
 
   int stage = 0;
   for (int t = 0; t < nsteps; ++t) {
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     // refill the stage that step t-1 vacated (every wave passed the barrier, so nobody reads it any more)
-    issue(stage == 0 ? NS - 1 : stage - 1, m_begin + (t + NS - 1) * BKP);
+    issue(stage == 0 ? NS - 1 : stage - 1);
     const char* yb = smem + stage * STAGE;
     const char* xb = yb + YBYTES;
     {
