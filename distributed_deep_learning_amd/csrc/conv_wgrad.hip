@@ -318,7 +318,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   //      pixel plus a constant, with (p, q) carried incrementally (32 = qa * Q + qb: one conditional wrap each).  The
   //      per-stage decode this replaces was two magic-number divisions and ~8 quarter-rate integer multiplies per DMA,
   //      about as many issue cycles as the stage's 16 MFMAs.
-  const bool same = !p.plain && p.stride == 1 && p.P == p.H && p.Q == p.W;      // wave-uniform
+  // (the single conditional wrap of p needs qa + 1 <= P: images of at least ~6x6; smaller ones decode per stage)
+  const bool same = !p.plain && p.stride == 1 && p.P == p.H && p.Q == p.W && BKP / p.Q + 1 <= p.P;      // wave-uniform
   const int qa = BKP / p.Q, qb = BKP - qa * p.Q;
   const int dr = r - p.pad, ds = xs - p.pad;
   int mcur = m_begin;
