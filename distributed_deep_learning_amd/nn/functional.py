@@ -134,8 +134,8 @@ class ConvBNReluPool(torch.autograd.Function):
         y_conv, vec = K.conv2d_fwd_bn(x, w_krsc, stride, pad, gamma, beta, running_mean, running_var, momentum, eps,
                                       slabs[0] if slabs else K.new_slab(w_krsc.shape[0], x.device))
         rows = K.vec_rows(vec)
-        out, idx = K.bn_relu_maxpool_fwd(y_conv, rows[2], rows[3], *pool)
-        ctx.save_for_backward(x, y_conv, idx, vec, gamma, w_crsk)
+        out, idx, aux = K.bn_relu_maxpool_fwd(y_conv, rows[2], rows[3], *pool, want_aux=True)
+        ctx.save_for_backward(x, y_conv, idx, vec, gamma, w_crsk, *aux)
         ctx.geom = (stride, pad, w_krsc.shape[1], w_krsc.shape[2], cin_real, pool)
         ctx.weight = weight
         ctx.bn_params = (gamma, beta)
@@ -144,13 +144,13 @@ class ConvBNReluPool(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, y_conv, idx, vec, gamma, w_crsk = ctx.saved_tensors
+        x, y_conv, idx, vec, gamma, w_crsk, zmax, pmask = ctx.saved_tensors
         stride, pad, R, S, cin_real, pool = ctx.geom
         dout = K.nhwc(_bf16(dout))
         rows = K.vec_rows(vec)
         arena, gout = _bn_grad_out(*ctx.bn_params)
         dconv, dgamma, dbeta = K.bn_relu_maxpool_bwd(dout, idx, y_conv, gamma, rows[0], rows[1], *pool, slab=ctx.slab,
-                                                     grad_out=gout)
+                                                     grad_out=gout, aux=(zmax, pmask))
         if arena is not None:
             arena.notify_grad_ready(ctx.bn_params[0])
             arena.notify_grad_ready(ctx.bn_params[1])

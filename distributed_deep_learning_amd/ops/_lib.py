@@ -43,8 +43,8 @@ _SIGS = {
     "ddl_bn_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_bn_backward": [_vp] * 12 + [_i, _i, _i, _i, _i, _vp],
     "ddl_bn_backward_pair": [_vp] * 20 + [_i, _i, _i, _i, _vp],
-    "ddl_bn_relu_maxpool_fwd": [_vp, _vp, _vp, _vp, _vp] + [_i] * 9 + [_vp],
-    "ddl_bn_relu_maxpool_bwd": [_vp] * 11 + [_i] * 10 + [_vp],
+    "ddl_bn_relu_maxpool_fwd": [_vp] * 7 + [_i] * 9 + [_vp],
+    "ddl_bn_relu_maxpool_bwd": [_vp] * 13 + [_i] * 10 + [_vp],
     "ddl_maxpool_fwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
     "ddl_maxpool_bwd": [_vp, _vp, _vp] + [_i] * 9 + [_vp],
     "ddl_avgpool_fwd": [_vp, _vp] + [_i] * 8 + [_vp],

@@ -496,10 +496,12 @@ def bn_backward_pair(dy, mask, xa, xb, stat_a, stat_b, relu=True, slabs=None, gr
     return dxa, dxb, ga, gb
 
 
-def bn_relu_maxpool_fwd(x, scale, shift, k, stride, pad):
+def bn_relu_maxpool_fwd(x, scale, shift, k, stride, pad, want_aux=False):
     """``maxpool(relu(x*scale + shift))`` straight from the conv output ``x``: returns ``(y_pool, idx)`` — the
     full-resolution activation is never written.  ``idx`` (uint8, shape of ``y_pool``) feeds
-    :func:`bn_relu_maxpool_bwd`."""
+    :func:`bn_relu_maxpool_bwd`.  ``want_aux``: also returns ``(zmax, pmask)`` — the raw ``x`` at every argmax (bf16,
+    shape of ``y_pool``) and one gate byte per 8 pooled channels — with which the backward takes its two sums over the
+    pooled tensors instead of gathering 1-4 (gradient, argmax) pairs for every full-resolution pixel."""
     lib = _lib.require()
     _chk_act(x, "bn_relu_maxpool_fwd")
     x = nhwc(x)
@@ -509,14 +511,19 @@ def bn_relu_maxpool_fwd(x, scale, shift, k, stride, pad):
         raise ValueError("bn_relu_maxpool_fwd: padding larger than half the window")
     y = torch.empty((N, Cc, P, Q), dtype=BF16, device=x.device, memory_format=CL)
     idx = torch.empty((N, P, Q, Cc), dtype=torch.uint8, device=x.device)
-    check(lib.ddl_bn_relu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(idx), N, H, W, Cc, P, Q, k, stride, pad,
-                                      stream_ptr()), "bn_relu_maxpool_fwd")
-    return y, idx
+    zmax = pmask = None
+    if want_aux:
+        zmax = torch.empty((N, P, Q, Cc), dtype=BF16, device=x.device)
+        pmask = torch.empty((N * P * Q, Cc // 8), dtype=torch.uint8, device=x.device)
+    check(lib.ddl_bn_relu_maxpool_fwd(ptr(x), ptr(scale), ptr(shift), ptr(y), ptr(idx), ptr(zmax), ptr(pmask), N, H, W, Cc,
+                                      P, Q, k, stride, pad, stream_ptr()), "bn_relu_maxpool_fwd")
+    return (y, idx, (zmax, pmask)) if want_aux else (y, idx)
 
 
-def bn_relu_maxpool_bwd(dp, idx, x, gamma, mean, invstd, k, stride, pad, slab=None, grad_out=None):
+def bn_relu_maxpool_bwd(dp, idx, x, gamma, mean, invstd, k, stride, pad, slab=None, grad_out=None, aux=None):
     """Backward of conv-output -> BN -> ReLU -> max-pool as one unit: ``dp`` is the gradient of the POOLED output.
-    Returns ``(dx, dgamma, dbeta)`` with ``dx`` the gradient of the conv output ``x``."""
+    Returns ``(dx, dgamma, dbeta)`` with ``dx`` the gradient of the conv output ``x``.  ``aux``: the ``(zmax, pmask)``
+    pair of :func:`bn_relu_maxpool_fwd` (pooled-domain reduction)."""
     lib = _lib.require()
     _chk_act(dp, "bn_relu_maxpool_bwd")
     dp, x = nhwc(dp), nhwc(x)
@@ -536,7 +543,11 @@ def bn_relu_maxpool_bwd(dp, idx, x, gamma, mean, invstd, k, stride, pad, slab=No
     if slab is None:
         slab = new_slab(Cc, x.device)
     coef = _slab_scratch(slab, Cc)
-    check(lib.ddl_bn_relu_maxpool_bwd(ptr(dp), ptr(idx), ptr(x), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
+    zmax, pmask = aux if aux is not None else (None, None)
+    if zmax is not None and (zmax.numel() != dp.numel() or zmax.dtype != BF16 or pmask.dtype != torch.uint8
+                             or pmask.numel() * 8 != dp.numel() or not zmax.is_contiguous() or not pmask.is_contiguous()):
+        raise ValueError("bn_relu_maxpool_bwd: aux must be the (zmax, pmask) pair of bn_relu_maxpool_fwd")
+    check(lib.ddl_bn_relu_maxpool_bwd(ptr(dp), ptr(idx), ptr(x), ptr(zmax), ptr(pmask), ptr(gamma), ptr(mean), ptr(invstd), ptr(dx), ptr(dg),
                                       ptr(db), ptr(slab), coef, N, H, W, Cc, P, Q, k, stride, pad,
                                       int(grad_out is not None), stream_ptr()), "bn_relu_maxpool_bwd")
     return dx, dg, db

@@ -278,9 +278,11 @@ def test_relu_bwd_bias_grad_fused(shape):
     _close(acc, 1.0 + ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2, what="bias grad accumulate")
 
 
+@pytest.mark.parametrize("pooled_sums", [False, True], ids=["gather-sums", "pooled-sums"])
 @pytest.mark.parametrize("shape,pool", [((2, 64, 16, 16), (3, 2, 1)), ((3, 32, 9, 11), (3, 2, 1)), ((2, 16, 8, 8), (2, 2, 0))])
-def test_bn_relu_maxpool_fused_unit(shape, pool):
-    """maxpool(relu(bn(x))) forward + its BN backward from the POOLED gradient vs autograd on fp32 torch ops."""
+def test_bn_relu_maxpool_fused_unit(shape, pool, pooled_sums):
+    """maxpool(relu(bn(x))) forward + its BN backward from the POOLED gradient vs autograd on fp32 torch ops; the two
+    backward sums taken by gathering per full-resolution pixel, or over the pooled tensors (zmax / pmask of the forward)."""
     from distributed_deep_learning_amd.ops import kernels as K
 
     N, C, H, W = shape
@@ -290,7 +292,11 @@ def test_bn_relu_maxpool_fused_unit(shape, pool):
     beta = (torch.randn(C, generator=torch.Generator().manual_seed(23)) * 0.3).to(_dev())
     slab = K.bn_stats(x)
     vec = K.bn_finalize(slab, N * H * W, gamma, beta, None, None, 0.1, 1e-5)
-    y, idx = K.bn_relu_maxpool_fwd(x, vec[2], vec[3], k, s, p)
+    aux = None
+    if pooled_sums:
+        y, idx, aux = K.bn_relu_maxpool_fwd(x, vec[2], vec[3], k, s, p, want_aux=True)
+    else:
+        y, idx = K.bn_relu_maxpool_fwd(x, vec[2], vec[3], k, s, p)
 
     xr = x.float().requires_grad_(True)
     gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
@@ -298,7 +304,7 @@ def test_bn_relu_maxpool_fused_unit(shape, pool):
     _close(y, ref, what="fused bn+relu+maxpool fwd")
     dp = _rand_act(tuple(y.shape), 24)
     ref.backward(dp.float())
-    dx, dg, db = K.bn_relu_maxpool_bwd(dp, idx, x, gamma, vec[0], vec[1], k, s, p)
+    dx, dg, db = K.bn_relu_maxpool_bwd(dp, idx, x, gamma, vec[0], vec[1], k, s, p, aux=aux)
     _close(dg, gr.grad, rtol=2e-2, atol=2e-2 * max(1.0, gr.grad.abs().max().item()), what="dgamma")
     _close(db, br.grad, rtol=2e-2, atol=2e-2 * max(1.0, br.grad.abs().max().item()), what="dbeta")
     # bf16 ties in the pooled max can route a gradient to a different pixel of the window: compare in aggregate
