@@ -63,6 +63,8 @@ def _bn_bwd(dout, mask, x_bn, gamma_p, beta_p, gamma, mean, invstd, relu, want_d
 
 
 _PAIR_BN = os.environ.get("DDL_BN_PAIR", "1") != "0"
+# forward: projection-shortcut conv on the side stream, beside the main path's first units (A/B switch)
+_FORK_SHORTCUT = os.environ.get("DDL_FORK_SHORTCUT", "1") != "0"
 # BN-backward sums taken in the producing dgrad's epilogue (skips the reduce pass of the in-block BNs).  Measured on
 # ResNet-50, B=512: 13.41k img/s with it vs 13.49-13.54k without - the extra epilogue work (z + mask reads, LDS
 # reduction, atomics) sits on the critical path of short 1x1 dgrads and costs more than the bandwidth-bound reduce
@@ -194,14 +196,23 @@ class ResidualBlock(torch.autograd.Function):
             return out if apply else (y_conv, rows[2], rows[3])
 
         identity, ds_affine = x, None
+        forked = False
         if ds is not None:
             # projection shortcut: only conv + statistics here; its BN affine is applied to the raw conv output inside
-            # the last unit's apply pass, so the normalised shortcut is neither written nor read back
-            identity, sc, sh = run(ds[0], ds[1], x, False, None, apply=False)
+            # the last unit's apply pass, so the normalised shortcut is neither written nor read back.  Nothing but
+            # that last apply pass needs it: it runs on the side stream, beside the main path's first units.
+            if _FORK_SHORTCUT and x.is_cuda and len(units) > 1 and streams.enabled():
+                with streams.fork(x):
+                    identity, sc, sh = run(ds[0], ds[1], x, False, None, apply=False)
+                forked = True
+            else:
+                identity, sc, sh = run(ds[0], ds[1], x, False, None, apply=False)
             ds_affine = (sc, sh)
         h = x
         for i, (conv, bn) in enumerate(units):
             last = i == len(units) - 1
+            if last and forked:
+                streams.join()
             h = run(conv, bn, h, True, identity if last else None, ds_affine if last else None)
         ctx.save_for_backward(*saved)
         ctx.metas = metas
@@ -288,6 +299,7 @@ class ResidualBlock(torch.autograd.Function):
                 fconv = metas[first_main][0]
                 compact = (step > 1 and dsc.kernel_size == (1, 1) and dsc.padding[0] == 0
                            and fconv.stride[0] == 1)          # first main conv writes every input pixel in one launch
+                # (issuing this dgrad early on the side stream, behind an event, was measured: no gain over the forward fork)
                 dshort, _ = back(0, dout, need_x, relu_mask=out_mask, compact_dx=compact, bn_done=ds_done)
                 dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None,
                              addend_step=step if compact else 1, presummed=pre)
