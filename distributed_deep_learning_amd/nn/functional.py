@@ -63,6 +63,14 @@ def _bn_bwd(dout, mask, x_bn, gamma_p, beta_p, gamma, mean, invstd, relu, want_d
 
 
 _PAIR_BN = os.environ.get("DDL_BN_PAIR", "1") != "0"
+# Backward launch order of a conv unit: filter gradient (side stream) BEFORE the data gradient (main stream).  Both read
+# the same output gradient, which the BatchNorm-backward apply pass has just written: launched in this order they run
+# side by side and the second reader finds the tensor in the caches (ResNet-50, batch 512: 38.07 -> 37.40 ms; deferring
+# the filter gradient by one unit instead: 37.55-37.75 ms; by two: 37.9 ms).  DDL_WGRAD_FIRST=0: data gradient first.
+_WGRAD_FIRST = os.environ.get("DDL_WGRAD_FIRST", "1") != "0"
+# conv + bias + ReLU units (VGG, LeNet): measured the other way round (VGG-16, batch 128: 17.8 ms data gradient first,
+# 18.07 ms filter gradient first - the gated dgrad's epilogue also feeds the NEXT unit's bias gradient), so they keep it
+_WGRAD_FIRST_PLAIN = os.environ.get("DDL_WGRAD_FIRST_PLAIN", "0") != "0"
 # forward: projection-shortcut conv on the side stream, beside the main path's first units (A/B switch)
 _FORK_SHORTCUT = os.environ.get("DDL_FORK_SHORTCUT", "1") != "0"
 # BN-backward sums taken in the producing dgrad's epilogue (skips the reduce pass of the in-block BNs).  Measured on
@@ -119,9 +127,11 @@ class ConvBNAct(torch.autograd.Function):
         dconv, dres, dgamma, dbeta = _bn_bwd(dout, mask, y_conv, ctx.bn_params[0], ctx.bn_params[1], gamma, vec[0],
                                              vec[1], relu, has_res, ctx.slab)
         dx = None
+        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real) if _WGRAD_FIRST else None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dconv, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
+        if not _WGRAD_FIRST:
+            dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
         return (dx, dw, dgamma, dbeta, dres) + (None,) * 11
 
 
@@ -158,9 +168,11 @@ class ConvBNReluPool(torch.autograd.Function):
             arena.notify_grad_ready(ctx.bn_params[1])
             dgamma = dbeta = None
         dx = None
+        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real) if _WGRAD_FIRST else None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dconv, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
+        if not _WGRAD_FIRST:
+            dw = _wgrad(ctx.weight, dconv, x, R, S, stride, pad, cin_real)
         return (dx, dw, dgamma, dbeta) + (None,) * 11
 
 
@@ -242,6 +254,9 @@ class ResidualBlock(torch.autograd.Function):
                 dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
                                                      relu, want_dres, slab, presummed)
             dx = None
+            R, S = conv.kernel_size
+            dw = (_wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
+                  if _WGRAD_FIRST else None)
             if need_dx and compact_dx:
                 # strided 1x1 conv: its input gradient is non-zero only on the stride grid -> compute just that grid
                 # (a plain stride-1 dgrad over the output pixels); the consumer adds it with ``addend_step``
@@ -249,8 +264,8 @@ class ResidualBlock(torch.autograd.Function):
             elif need_dx:
                 dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend,
                                     addend_mask=addend_mask, addend_step=addend_step, bn_sums=sums_for)
-            R, S = conv.kernel_size
-            dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
+            if not _WGRAD_FIRST:
+                dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
             grads[idx] = (dw, dgamma, dbeta)
             return dx, dres
 
@@ -397,12 +412,18 @@ class DenseBlock(torch.autograd.Function):
             r1, r2 = K.vec_rows(vec1), K.vec_rows(vec2)
             dy2 = torch.empty((N, g, H, W), dtype=BF16, device=buf.device, memory_format=torch.channels_last)
             K.copy_channels(K.ChannelWindow(src, cin, g), dy2)
+            dw2 = (_wgrad(c2.weight, dy2, a2, *c2.kernel_size, c2.stride[0], c2.padding[0], c2.in_channels)
+                   if _WGRAD_FIRST else None)
             da2 = K.conv2d_dgrad(dy2, t2, (H, W), c2.stride[0], c2.padding[0])
-            dw2 = _wgrad(c2.weight, dy2, a2, *c2.kernel_size, c2.stride[0], c2.padding[0], c2.in_channels)
+            if not _WGRAD_FIRST:
+                dw2 = _wgrad(c2.weight, dy2, a2, *c2.kernel_size, c2.stride[0], c2.padding[0], c2.in_channels)
             dz1, _, dg2, db2 = _bn_bwd(da2, m2, z1, n2.weight, n2.bias, n2.weight, r2[0], r2[1], True, False,
                                        n2.slabs(buf.device)[1])
+            dw1 = (_wgrad(c1.weight, dz1, a1, *c1.kernel_size, c1.stride[0], c1.padding[0], c1.in_channels)
+                   if _WGRAD_FIRST else None)
             da1 = K.conv2d_dgrad(dz1, t1, (H, W), c1.stride[0], c1.padding[0])
-            dw1 = _wgrad(c1.weight, dz1, a1, *c1.kernel_size, c1.stride[0], c1.padding[0], c1.in_channels)
+            if not _WGRAD_FIRST:
+                dw1 = _wgrad(c1.weight, dz1, a1, *c1.kernel_size, c1.stride[0], c1.padding[0], c1.in_channels)
             arena, gout = _bn_grad_out(n1.weight, n1.bias)
             dg1, db1 = K.bn_backward_window(da1, m1, K.ChannelWindow(buf, 0, cin), n1.weight, r1[0], r1[1],
                                             K.ChannelWindow(gbuf, 0, cin), add_to=K.ChannelWindow(src, 0, cin),
@@ -478,9 +499,11 @@ class ConvBiasAct(torch.autograd.Function):
         if padded and db is not None:
             db = db[:k_real]
         dx = None
+        dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real, k_real) if _WGRAD_FIRST_PLAIN else None
         if ctx.needs_input_grad[0]:
             dx = K.conv2d_dgrad(dy, w_crsk, tuple(x.shape[2:]), stride, pad)
-        dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real, k_real)
+        if not _WGRAD_FIRST_PLAIN:
+            dw = _wgrad(ctx.weight, dy, x, R, S, stride, pad, cin_real, k_real)
         return (dx, dw, db) + (None,) * 7
 
 
@@ -537,6 +560,8 @@ class ConvReluChain(torch.autograd.Function):
                     d, grads[2 * i + 1] = K.relu_bwd_bias_grad(d, y)
             R, S = conv.kernel_size
             stride, pad = conv.stride[0], conv.padding[0]
+            if _WGRAD_FIRST_PLAIN:
+                grads[2 * i] = _wgrad(conv.weight, d, x_in, R, S, stride, pad, conv.in_channels)
             dx = None
             gated = False
             if i > 0 or ctx.needs_input_grad[0]:
@@ -556,7 +581,8 @@ class ConvReluChain(torch.autograd.Function):
                     gated = True
                 else:
                     dx = K.conv2d_dgrad(d, crsk, tuple(x_in.shape[2:]), stride, pad)
-            grads[2 * i] = _wgrad(conv.weight, d, x_in, R, S, stride, pad, conv.in_channels)
+            if not _WGRAD_FIRST_PLAIN:
+                grads[2 * i] = _wgrad(conv.weight, d, x_in, R, S, stride, pad, conv.in_channels)
             d = dx
         return (d, None, *grads)
 
