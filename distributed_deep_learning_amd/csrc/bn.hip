@@ -554,6 +554,79 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// Apply pass of the fused BN + ReLU + max-pool unit for the 3x3 / stride 2 / pad 1 pool on an even-sized image (ResNet's
+// stem): one thread owns a 2x2 QUAD of full-resolution pixels (one 8-channel chunk).  The four pooled windows that can
+// have picked any of them - (a, b), (a, b+1), (a+1, b), (a+1, b+1) for the quad at (2a, 2b) - are loaded ONCE (gradient +
+// argmax bytes) instead of 1, 2, 2 and 4 times by four independent pixels: 1.0 instead of 2.25 window loads per pixel.
+__global__ __launch_bounds__(256) void bn_pool_bwd_apply_quad_kernel(const bf16_t* __restrict__ dp,
+                                                                    const unsigned char* __restrict__ idx,
+                                                                    const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
+                                                                    const float* __restrict__ coefA,
+                                                                    const float* __restrict__ coefB,
+                                                                    const float* __restrict__ coefC, int N, int H, int W,
+                                                                    int C, int P, int Q, long long total) {
+  const int c8 = C >> 3, H2 = H >> 1, W2 = W >> 1;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int chunk = (int)(t % c8);
+    long long r = t / c8;
+    const int b = (int)(r % W2); r /= W2;
+    const int a = (int)(r % H2);
+    const int n = (int)(r / H2);
+    float ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = coefA[chunk * 8 + e]; cb[e] = coefB[chunk * 8 + e]; cc[e] = coefC[chunk * 8 + e]; }
+    float g[2][2][8];
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[dh][dw][e] = 0.f;
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp) {
+      const int p = a + wp;
+      if (p >= P) continue;
+#pragma unroll
+      for (int wq = 0; wq < 2; ++wq) {
+        const int q = b + wq;
+        if (q >= Q) continue;
+        const size_t o = (((size_t)n * P + p) * Q + q) * C + (size_t)chunk * 8;
+        const u32x2 pk = *reinterpret_cast<const u32x2*>(idx + o);
+        float gf[8];
+        unpack8(*reinterpret_cast<const u32x4*>(dp + o), gf);
+        // pixel (2a + dh, 2b + dw) sits at window position i = dh + 1 - 2 wp, j = dw + 1 - 2 wq (inside the 3x3 window iff 0..2)
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+          const int i = dh + 1 - 2 * wp;
+          if (i < 0) continue;
+#pragma unroll
+          for (int dw = 0; dw < 2; ++dw) {
+            const int j = dw + 1 - 2 * wq;
+            if (j < 0) continue;
+            const unsigned me = (unsigned)(i * 3 + j);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const unsigned bsel = ((e < 4 ? pk[0] : pk[1]) >> ((e & 3) * 8)) & 0xffu;
+              if (bsel == me) g[dh][dw][e] += gf[e];
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const size_t off = (((size_t)n * H + (size_t)(2 * a + dh)) * W + (size_t)(2 * b + dw)) * C + (size_t)chunk * 8;
+        float xf[8], ov[8];
+        unpack8(ld_stream(x + off), xf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ov[e] = ca[e] * g[dh][dw][e] + cb[e] * xf[e] + cc[e];
+        *reinterpret_cast<u32x4*>(dx + off) = pack8(ov);
+      }
+  }
+}
+
 // ---------------------------------------------------------------- backward of TWO BatchNorms behind one gradient
 // A projection block ends in  out = relu(BN_a(z_a) + BN_b(z_b))  (last main-path BN + shortcut BN): both backward
 // passes consume the same dy and the same ReLU mask.  These variants read them ONCE per pass for both normalisations.
@@ -980,6 +1053,13 @@ extern "C" int ddl_bn_relu_maxpool_bwd(const void* dp, const void* idx, const vo
   if (fslots == 0 || zmax != nullptr)
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(256), 0, st, slab, BN_SLOTS, C, (float)M, gamma,
                        mean, invstd, dgamma, dbeta, accumulate, cA, cB, cC);
+  static const int quad_on = [] { const char* e = getenv("DDL_POOL_QUAD"); return e ? atoi(e) : 1; }();
+  if (quad_on && k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && P == H / 2 && Q == W / 2) {
+    const long long total = (long long)N * (H / 2) * (W / 2) * (C / 8);
+    hipLaunchKernelGGL(bn_pool_bwd_apply_quad_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, st, dpp, ip, xp,
+                       (bf16_t*)dx, cA, cB, cC, N, H, W, C, P, Q, total);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL((bn_bwd_apply_kernel<true, false, true>), grid, dim3(256), 0, st, dpp, ip, xp, (bf16_t*)dx,
                      (bf16_t*)nullptr, cA, cB, cC, rm, pm);
   return (int)hipGetLastError();
