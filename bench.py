@@ -31,7 +31,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # stock PyTorch-ROCm ResNet-50 (bench/stock_models.py) on the same MI355X, img/s per GPU, keyed by per-GPU batch
-STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6793.5}
+STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6794.3}
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -39,9 +39,11 @@ def build_parser() -> argparse.ArgumentParser:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=1024,
-                    help="per-GPU batch size (sized for 288 GB HBM; measured img/s on one MI355X: 256: 12.7k, 512: 13.4k, "
-                         "640: 13.7k, 1024: 13.8k)")
+    ap.add_argument("--batch", type=int, default=1000,
+                    help="per-GPU batch size (sized for 288 GB HBM and for the conv tiles: the 256-pixel tiles of the 14x14 "
+                         "layers fill the 512 resident block slots in exactly 3 rounds up to batch 1003 and need a 4th, 6 %% "
+                         "full, from 1004 on; measured img/s on one MI355X: 256: 13.0k, 512: 13.7k, 668: 13.8k, 1000: 13.85k, "
+                         "1024: 13.75k, 1336: 13.8k)")
     ap.add_argument("--model", default="resnet50")
     ap.add_argument("--sync", default="allreduce", choices=["allreduce", "ps"])
     ap.add_argument("--optimizer", default="sgd", choices=["sgd", "lars"])

@@ -5,7 +5,8 @@ OUT=gpurun_out; mkdir -p $OUT
 F=$OUT/final_numbers.txt; : > $F
 line() { grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"reserved_gib": [0-9.]*' | paste -sd' ' ; }
 run() { local tag=$1; shift; local o; o=$(timeout -k 10 400 python bench.py --steps 20 --warmup 5 "$@" 2>&1 | tail -1 | line); rc=$?; echo "$tag | $o" | tee -a $F; }
-run "resnet50 B=1024 (default)"
+run "resnet50 B=1000 (default)"
+run "resnet50 B=1024" --batch 1024
 run "resnet50 B=512" --batch 512
 run "resnet50 B=256" --batch 256
 run "resnet50 B=512 forced collectives native" --batch 512 --force-collectives --comm native
