@@ -24,7 +24,7 @@ struct WgradParams {
   int M, SC;
   int tiles_k, tiles_n, splits, m_per_split;
   int plain;          // 1x1, stride 1, pad 0: x row index == m
-  FastDiv div_pq, div_q, div_c;
+  FastDiv div_pq, div_q, div_c, div_sc;
   unsigned long long dy_bytes, x_bytes;   // operand sizes (buffer descriptors of the LDS-DMA kernel)
 };
 
@@ -260,19 +260,26 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+  else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-template <int TK, int TN>
+// NSUB = 2 ("fold R"): the X tile is TWO TN-wide sub-tiles side by side and the column index runs over ALL filter rows,
+// nn = (r, s, c) in [0, R*S*C): one block accumulates the whole [TK][R*S*C] slice of the filter gradient, so dy is staged
+// once instead of once per filter row (grid dimension R collapses to 1).  For small filters on few channels (ResNet's
+// space-to-depth stem: 4x4 taps x 16 channels = 256 columns, where the per-row version streams dy four times through L2).
+template <int TK, int TN, int NSUB = 1>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams p) {
+  constexpr bool FOLD = NSUB > 1;
   constexpr int BKP = 32;                        // pixels per ring stage
   constexpr int NS = WG_RING_STAGES;             // ring stages (NS - 1 in flight)
   constexpr int YROWB = TK * 2, XROWB = TN * 2;  // bytes per tile row
   constexpr int YRW = 1024 / YROWB, XRW = 1024 / XROWB;      // rows per LDS-DMA wave-instruction (4 or 8)
   constexpr int YJ = BKP / (4 * YRW), XJ = BKP / (4 * XRW);  // instructions per thread per stage (2 or 1)
-  constexpr int YBYTES = BKP * YROWB, XBYTES = BKP * XROWB, STAGE = YBYTES + XBYTES;
-  constexpr int WK = TK / 2, WN = TN / 2;
+  constexpr int XSUB = BKP * XROWB;                            // bytes of one X sub-tile
+  constexpr int YBYTES = BKP * YROWB, XBYTES = XSUB * NSUB, STAGE = YBYTES + XBYTES;
+  constexpr int WK = TK / 2, WN = TN * NSUB / 2;
   constexpr int FK = WK / 16, FN = WN / 16;
   constexpr unsigned OOB = 0xFFFFFFF0u;
 
@@ -285,7 +292,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   unsigned b = xcd_remap(blockIdx.x, gridDim.x);
   const int tn = b % p.tiles_n; b /= p.tiles_n;
   const int tk = b % p.tiles_k; b /= p.tiles_k;
-  const int r = b % p.R; b /= p.R;
+  const int r = FOLD ? 0 : (int)(b % p.R);
+  if (!FOLD) b /= p.R;
   const int split = (int)b;
   const int k0 = tk * TK, nn0 = tn * TN;
   const int m_begin = split * p.m_per_split;
@@ -306,24 +314,32 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   if (TN == 128) xch = xphys ^ (((xrow & 3) << 2) | (wid & 3));
   else           xch = xphys ^ ((((xrow >> 1) & 1) << 1) | ((wid & 1) << 2));
   const bool ycol_ok = (k0 + ych * 8) < p.K;
-  const int nn = nn0 + xch * 8;
-  const bool xcol_ok = nn < p.SC;
-  const int xs = (int)fastdiv((unsigned)nn, p.div_c);
-  const int xc = nn - xs * p.C;
   const unsigned ycol_off = (unsigned)(k0 + ych * 8);
+  // column (r, s, c) of this lane's 8-channel chunk, per sub-tile
+  bool xcol_ok[NSUB];
+  int xs[NSUB], xc[NSUB], xr[NSUB];
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) {
+    const int nn = nn0 + u * TN + xch * 8;
+    xcol_ok[u] = nn < (FOLD ? p.R * p.SC : p.SC);
+    const int rr = FOLD ? (int)fastdiv((unsigned)nn, p.div_sc) : r;
+    const int rest = nn - (FOLD ? rr * p.SC : 0);
+    xr[u] = rr;
+    xs[u] = (int)fastdiv((unsigned)rest, p.div_c);
+    xc[u] = rest - xs[u] * p.C;
+  }
 
   // ---- load cursor.  Stages are issued strictly in order, 32 pixels apart, so nothing is decoded per stage: byte offsets
-  //      advance by a constant, the row-in-range test is one compare against a scalar, and for "same" convolutions
-  //      (stride 1, output grid == input grid: every 3x3 of ResNet / VGG) the input pixel of tap (r, s) is the output
-  //      pixel plus a constant, with (p, q) carried incrementally (32 = qa * Q + qb: one conditional wrap each).  The
-  //      per-stage decode this replaces was two magic-number divisions and ~8 quarter-rate integer multiplies per DMA,
-  //      about as many issue cycles as the stage's 16 MFMAs.
+  //      advance by a constant, the row-in-range test is one compare against a scalar, and for stride-1 convolutions the
+  //      input pixel of tap (r, s) is  n*H*W + (p - pad + r)*W + (q - pad + s)  with (p, q) carried incrementally
+  //      (32 = qa * Q + qb: one conditional wrap of q, worth W - Q input pixels, and one of p, worth (H - P) * W; both
+  //      are zero for the "same" 3x3 convs of ResNet / VGG).  The per-stage decode this replaces was two magic-number
+  //      divisions and ~8 quarter-rate integer multiplies per DMA, about as many issue cycles as the stage's 16 MFMAs.
   // (the single conditional wrap of p needs qa + 1 <= P: images of at least ~6x6; smaller ones decode per stage)
-  const bool same = !p.plain && p.stride == 1 && p.P == p.H && p.Q == p.W && BKP / p.Q + 1 <= p.P;      // wave-uniform
+  const bool s1 = !p.plain && p.stride == 1 && BKP / p.Q + 1 <= p.P;      // wave-uniform
   const int qa = BKP / p.Q, qb = BKP - qa * p.Q;
-  const int dr = r - p.pad, ds = xs - p.pad;
   int mcur = m_begin;
-  unsigned yoff[YJ], xoff[XJ];
+  unsigned yoff[YJ], xoff[NSUB][XJ];
   int ycm[YJ], xcm[XJ], xp[XJ], xq[XJ];
 #pragma unroll
   for (int j = 0; j < YJ; ++j) {
@@ -336,16 +352,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
     const int m = m_begin + xcm[j];
     xp[j] = 0; xq[j] = 0;
     if (p.plain) {
-      xoff[j] = ((unsigned)m * (unsigned)p.C + (unsigned)xc) * 2u;
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) xoff[u][j] = ((unsigned)m * (unsigned)p.C + (unsigned)xc[u]) * 2u;
     } else {
       const unsigned n = fastdiv((unsigned)m, p.div_pq);
       const unsigned rem = (unsigned)m - n * p.div_pq.d;
       xp[j] = (int)fastdiv(rem, p.div_q);
       xq[j] = (int)rem - xp[j] * (int)p.div_q.d;
-      xoff[j] = ((unsigned)(m + dr * p.W + ds) * (unsigned)p.C + (unsigned)xc) * 2u;
+      const int rowbase = ((int)n * p.H + xp[j]) * p.W + xq[j];
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u)
+        xoff[u][j] = ((unsigned)(rowbase + (xr[u] - p.pad) * p.W + (xs[u] - p.pad)) * (unsigned)p.C + (unsigned)xc[u]) * 2u;
     }
   }
-  const unsigned ystep = (unsigned)(BKP * 2) * (unsigned)p.K, xstep = (unsigned)(BKP * 2) * (unsigned)p.C;
+  const unsigned ystep = (unsigned)(BKP * 2) * (unsigned)p.K;
+  const unsigned xstep = p.plain ? (unsigned)(BKP * 2) * (unsigned)p.C : (unsigned)((qa * p.W + qb) * 2) * (unsigned)p.C;
+  const unsigned qwrap = (unsigned)((p.W - p.Q) * 2) * (unsigned)p.C;                 // input pixels skipped when q wraps
+  const unsigned pwrap = (unsigned)((p.H - p.P) * p.W * 2) * (unsigned)p.C;           // ... when p wraps (next image)
 
   auto issue = [&](int stage) {
     const unsigned sb = smem_addr + (unsigned)(stage * STAGE);
@@ -357,31 +380,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
     }
 #pragma unroll
     for (int j = 0; j < XJ; ++j) {
-      unsigned off;
-      bool ok = xcol_ok && xcm[j] < lim;
+      const bool row_ok = xcm[j] < lim;
       if (p.plain) {                              // wave-uniform
-        off = xoff[j];
-        xoff[j] += xstep;
-      } else if (same) {                          // wave-uniform
-        const int ih = xp[j] + dr, iw = xq[j] + ds;
-        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        off = xoff[j];
-        xoff[j] += xstep;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + u * XSUB + (j * 4 + wid) * 1024), (xcol_ok[u] && row_ok) ? xoff[u][j] : OOB);
+          xoff[u][j] += xstep;
+        }
+      } else if (s1) {                            // wave-uniform
+        unsigned adv = xstep;
+        const int pq = xp[j], qq = xq[j];
         xq[j] += qb; xp[j] += qa;
-        if (xq[j] >= p.Q) { xq[j] -= p.Q; ++xp[j]; }
-        if (xp[j] >= p.P) xp[j] -= p.P;
+        if (xq[j] >= p.Q) { xq[j] -= p.Q; ++xp[j]; adv += qwrap; }
+        if (xp[j] >= p.P) { xp[j] -= p.P; adv += pwrap; }
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          const int ih = pq - p.pad + xr[u], iw = qq - p.pad + xs[u];
+          const bool ok = xcol_ok[u] && row_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+          wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + u * XSUB + (j * 4 + wid) * 1024), ok ? xoff[u][j] : OOB);
+          xoff[u][j] += adv;
+        }
       } else {                                    // branch-free: every lane decodes, invalid lanes read out of range
         const int m = mcur + xcm[j];
         const unsigned n = fastdiv((unsigned)m, p.div_pq);
         const unsigned rem = (unsigned)m - n * p.div_pq.d;
         const unsigned pp = fastdiv(rem, p.div_q);
         const unsigned qq = rem - pp * p.div_q.d;
-        const int ih = (int)pp * p.stride - p.pad + r;
-        const int iw = (int)qq * p.stride - p.pad + xs;
-        ok = ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        off = ((unsigned)((int)n * p.H * p.W + ih * p.W + iw) * (unsigned)p.C + (unsigned)xc) * 2u;
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          const int ih = (int)pp * p.stride - p.pad + xr[u];
+          const int iw = (int)qq * p.stride - p.pad + xs[u];
+          const bool ok = xcol_ok[u] && row_ok && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+          const unsigned off = ((unsigned)((int)n * p.H * p.W + ih * p.W + iw) * (unsigned)p.C + (unsigned)xc[u]) * 2u;
+          wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + u * XSUB + (j * 4 + wid) * 1024), ok ? off : OOB);
+        }
       }
-      wg_lds_dma16(xsrc, sb + (unsigned)(YBYTES + (j * 4 + wid) * 1024), ok ? off : OOB);
     }
     mcur += BKP;
   };
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
 
   const int g = lane >> 4, q4 = (lane & 15) >> 2, pp4 = lane & 3;
   const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
-  constexpr int PER = YJ + XJ;                   // loads per thread per stage
+  constexpr int PER = YJ + XJ * NSUB;            // loads per thread per stage
 
   // prologue: NS-1 stages in flight (stages past the end are all-zero fills, so the counted waits stay uniform)
 #pragma unroll
@@ -426,13 +459,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
       }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        const int c0 = (wn * WN + j * 16) >> 3;
+        const int col = wn * WN + j * 16;                    // column inside the (NSUB x TN)-wide X tile
+        const char* const xsb = xb + (col / TN) * XSUB;      // its sub-tile
+        const int c0 = (col % TN) >> 3;
         const int ch = c0 + (pp4 >> 1);
         const int sub = (pp4 & 1) * 8;
         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(xb + tr_off<TN>(rbase, ch) + sub));
+            (__attribute__((address_space(3))) s16x4*)(xsb + tr_off<TN>(rbase, ch) + sub));
         const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(xb + tr_off<TN>(rbase + 4, ch) + sub));
+            (__attribute__((address_space(3))) s16x4*)(xsb + tr_off<TN>(rbase + 4, ch) + sub));
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bfr[j] = __builtin_bit_cast(bf16x8, v);
       }
@@ -448,8 +483,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   __syncthreads();
 
   if (nsteps > 0) {
-    float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TN] fp32, reuses the ring
-    static_assert(TK * TN * 4 <= NS * STAGE, "epilogue tile must fit in the ring");
+    constexpr int TNW = TN * NSUB;
+    float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TNW] fp32, reuses the ring
+    static_assert(TK * TNW * 4 <= NS * STAGE, "epilogue tile must fit in the ring");
 #pragma unroll
     for (int i = 0; i < FK; ++i)
 #pragma unroll
@@ -458,16 +494,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int row = wk * WK + i * 16 + (lane >> 4) * 4 + e;
-          Ts[row * TN + col] = acc[i][j][e];
+          Ts[row * TNW + col] = acc[i][j][e];
         }
       }
     __syncthreads();
-    constexpr int LPR = TN / 64;
+    constexpr int LPR = TNW / 64;
     for (int it = wid; it < TK * LPR; it += 4) {
       const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
       const int k = k0 + row, cn = nn0 + col;
-      if (k < p.K && cn < p.SC)
-        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TN + col]);
+      if (FOLD) {                                  // cn runs over (r, s, c): the filter row is part of the column
+        if (k < p.K && cn < p.R * p.SC)
+          atomicAdd(p.dw + (size_t)k * (size_t)p.R * (size_t)p.SC + (size_t)cn, Ts[row * TNW + col]);
+      } else if (k < p.K && cn < p.SC) {
+        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TNW + col]);
+      }
     }
   }
 }
@@ -526,6 +566,27 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   return launch_wgrad_g<TK, TN, 1>(p, stream, smem, grid);
 }
 
+// Fold-R launch: one tile [64][R*S*C <= 256], every resident block slot is a split of M.
+static int launch_wgrad_fold(WgradParams& p, hipStream_t stream) {
+  constexpr int TK = 64, TN = 128, NSUB = 2;
+  p.tiles_k = 1; p.tiles_n = 1;
+  const int smem = WG_RING_STAGES * 32 * (TK + TN * NSUB) * 2;          // 2 blocks per CU at 4 stages
+  static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_FOLD_BLOCKS"); return e ? atoi(e) : 512; }();
+  long long splits = cap_env;
+  const long long max_splits = (p.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  long long mps = (p.M + splits - 1) / splits;
+  mps = ((mps + 63) / 64) * 64;
+  splits = (p.M + mps - 1) / mps;
+  p.splits = (int)splits;
+  p.m_per_split = (int)mps;
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB>), smem);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB>), dim3((unsigned)splits), dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
 // dw (fp32, [K][R][S][C]) must be zero on entry: the kernel accumulates with atomics.
 extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int P,
                               int Q, int R, int S, int stride, int pad, void* stream) {
@@ -540,9 +601,14 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
   p.div_pq = make_fastdiv((unsigned)(P * Q));
   p.div_q = make_fastdiv((unsigned)Q);
   p.div_c = make_fastdiv((unsigned)C);
+  p.div_sc = make_fastdiv((unsigned)(S * C));
   p.dy_bytes = (unsigned long long)M * K * 2ull;
   p.x_bytes = (unsigned long long)N * H * W * C * 2ull;
   hipStream_t st = (hipStream_t)stream;
+  // small filters on few channels (the space-to-depth stem: 4 x 4 x 16): all filter rows in one block, dy staged once
+  static const int fold_on = [] { const char* e = getenv("DDL_WGRAD_FOLD"); return e ? atoi(e) : 1; }();
+  if (fold_on && K <= 64 && R > 1 && R * p.SC <= 256 && R * p.SC > 128 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)
+    return launch_wgrad_fold(p, st);
   const bool k64 = K <= 64, n64 = p.SC <= 64 || (p.SC % 128 != 0 && p.SC % 64 == 0 && p.SC < 512);
   if (k64 && n64) return launch_wgrad<64, 64>(p, st);
   if (k64) return launch_wgrad<64, 128>(p, st);

@@ -44,6 +44,8 @@ CONV_CASES = [
     (1, 32, 20, 36, 96, 3, 1, 1),      # patch kernel: non-square, OC tail, single slice, M tail
     (4, 8, 28, 28, 8, 5, 1, 2),        # LeNet-5 conv1 (1 -> 6 channels, both padded to 8)
     (4, 8, 14, 14, 16, 5, 1, 0),       # LeNet-5 conv2 (6 -> 16)
+    (3, 64, 18, 21, 64, 3, 1, 0),      # unpadded 3x3: output grid smaller than input (filter-gradient cursor wraps)
+    (5, 16, 23, 19, 64, 4, 1, 0),      # space-to-depth stem shape, odd sizes (filter rows folded into the column index)
 ]
 
 
