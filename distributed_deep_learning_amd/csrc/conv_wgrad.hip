@@ -269,11 +269,11 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
 // nn = (r, s, c) in [0, R*S*C): one block accumulates the whole [TK][R*S*C] slice of the filter gradient, so dy is staged
 // once instead of once per filter row (grid dimension R collapses to 1).  For small filters on few channels (ResNet's
 // space-to-depth stem: 4x4 taps x 16 channels = 256 columns, where the per-row version streams dy four times through L2).
-template <int TK, int TN, int NSUB = 1>
+// NSUB = 2 without FOLD: a [TK][2*TN] tile of ONE filter row (25 % less LDS and fabric traffic per MFMA than 128 x 128).
+template <int TK, int TN, int NSUB = 1, bool FOLD = false, int NS_ = WG_RING_STAGES>
 __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams p) {
-  constexpr bool FOLD = NSUB > 1;
   constexpr int BKP = 32;                        // pixels per ring stage
-  constexpr int NS = WG_RING_STAGES;             // ring stages (NS - 1 in flight)
+  constexpr int NS = NS_;                        // ring stages (NS - 1 in flight)
   constexpr int YROWB = TK * 2, XROWB = TN * 2;  // bytes per tile row
   constexpr int YRW = 1024 / YROWB, XRW = 1024 / XROWB;      // rows per LDS-DMA wave-instruction (4 or 8)
   constexpr int YJ = BKP / (4 * YRW), XJ = BKP / (4 * XRW);  // instructions per thread per stage (2 or 1)
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
   const int r = FOLD ? 0 : (int)(b % p.R);
   if (!FOLD) b /= p.R;
   const int split = (int)b;
-  const int k0 = tk * TK, nn0 = tn * TN;
+  const int k0 = tk * TK, nn0 = tn * TN * NSUB;
   const int m_begin = split * p.m_per_split;
   const int m_end = min(p.M, m_begin + p.m_per_split);
 
@@ -484,29 +484,37 @@ __global__ __launch_bounds__(256) void conv_wgrad_ring_kernel(const WgradParams 
 
   if (nsteps > 0) {
     constexpr int TNW = TN * NSUB;
-    float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TNW] fp32, reuses the ring
-    static_assert(TK * TNW * 4 <= NS * STAGE, "epilogue tile must fit in the ring");
+    // fp32 tile through the ring, in EH passes of TK/EH rows when the whole tile does not fit
+    constexpr int EH = (TK * TNW * 4 + NS * STAGE - 1) / (NS * STAGE);
+    constexpr int WKH = WK / EH, FKH = FK / EH;
+    static_assert(EH >= 1 && FK % EH == 0 && (TK / EH) * TNW * 4 <= NS * STAGE, "epilogue pass must fit in the ring");
+    float* const Ts = reinterpret_cast<float*>(smem);          // [TK / EH][TNW] fp32, reuses the ring
 #pragma unroll
-    for (int i = 0; i < FK; ++i)
+    for (int h = 0; h < EH; ++h) {
+      if (h > 0) __syncthreads();
 #pragma unroll
-      for (int j = 0; j < FN; ++j) {
-        const int col = wn * WN + j * 16 + (lane & 15);
+      for (int ii = 0; ii < FKH; ++ii)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int row = wk * WK + i * 16 + (lane >> 4) * 4 + e;
-          Ts[row * TNW + col] = acc[i][j][e];
+        for (int j = 0; j < FN; ++j) {
+          const int col = wn * WN + j * 16 + (lane & 15);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int lr = wk * WKH + ii * 16 + (lane >> 4) * 4 + e;
+            Ts[lr * TNW + col] = acc[h * FKH + ii][j][e];
+          }
         }
-      }
-    __syncthreads();
-    constexpr int LPR = TNW / 64;
-    for (int it = wid; it < TK * LPR; it += 4) {
-      const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
-      const int k = k0 + row, cn = nn0 + col;
-      if (FOLD) {                                  // cn runs over (r, s, c): the filter row is part of the column
-        if (k < p.K && cn < p.R * p.SC)
-          atomicAdd(p.dw + (size_t)k * (size_t)p.R * (size_t)p.SC + (size_t)cn, Ts[row * TNW + col]);
-      } else if (k < p.K && cn < p.SC) {
-        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TNW + col]);
+      __syncthreads();
+      constexpr int LPR = TNW / 64;
+      for (int it = wid; it < (TK / EH) * LPR; it += 4) {
+        const int lr = it / LPR, col = (it - lr * LPR) * 64 + lane;
+        const int row = (lr / WKH) * WK + h * WKH + (lr % WKH);
+        const int k = k0 + row, cn = nn0 + col;
+        if (FOLD) {                                // cn runs over (r, s, c): the filter row is part of the column
+          if (k < p.K && cn < p.R * p.SC)
+            atomicAdd(p.dw + (size_t)k * (size_t)p.R * (size_t)p.SC + (size_t)cn, Ts[lr * TNW + col]);
+        } else if (k < p.K && cn < p.SC) {
+          atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[lr * TNW + col]);
+        }
       }
     }
   }
@@ -569,6 +577,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
 // Fold-R launch: one tile [64][R*S*C <= 256], every resident block slot is a split of M.
 static int launch_wgrad_fold(WgradParams& p, hipStream_t stream) {
   constexpr int TK = 64, TN = 128, NSUB = 2;
+  constexpr bool FOLD = true;
   p.tiles_k = 1; p.tiles_n = 1;
   const int smem = WG_RING_STAGES * 32 * (TK + TN * NSUB) * 2;          // 2 blocks per CU at 4 stages
   static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_FOLD_BLOCKS"); return e ? atoi(e) : 512; }();
@@ -581,9 +590,32 @@ static int launch_wgrad_fold(WgradParams& p, hipStream_t stream) {
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
   static SmemAttrOnce once;
-  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB>), smem);
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB, FOLD>), smem);
   if (rc != 0) return rc;
-  hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB>), dim3((unsigned)splits), dim3(256), smem, stream, p);
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB, FOLD>), dim3((unsigned)splits), dim3(256), smem, stream, p);
+  return (int)hipGetLastError();
+}
+
+// Wide launch: [128][256] tiles of one filter row, three ring stages (72 KiB: two blocks per CU, as the 128 x 128 tile).
+static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
+  constexpr int TK = 128, TN = 128, NSUB = 2, NS = 3;
+  p.tiles_k = (p.K + TK - 1) / TK;
+  p.tiles_n = (p.SC + TN * NSUB - 1) / (TN * NSUB);
+  const long long tiles = (long long)p.tiles_k * p.tiles_n * p.R;
+  const int smem = NS * 32 * (TK + TN * NSUB) * 2;
+  long long splits = capacity / tiles;
+  const long long max_splits = (p.M + 255) / 256;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long long mps = (p.M + splits - 1) / splits;
+  mps = ((mps + 63) / 64) * 64;
+  splits = (p.M + mps - 1) / mps;
+  p.splits = (int)splits;
+  p.m_per_split = (int)mps;
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB, false, NS>), smem);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB, false, NS>), dim3((unsigned)(tiles * splits)), dim3(256), smem, stream, p);
   return (int)hipGetLastError();
 }
 
@@ -610,6 +642,17 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
   if (fold_on && K <= 64 && R > 1 && R * p.SC <= 256 && R * p.SC > 128 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)
     return launch_wgrad_fold(p, st);
   const bool k64 = K <= 64, n64 = p.SC <= 64 || (p.SC % 128 != 0 && p.SC % 64 == 0 && p.SC < 512);
+  // Wide [128][256] tiles, ONE block per CU (256 resident blocks): the same bytes in flight as two 128 x 128 blocks with
+  // 25 % less LDS and fabric traffic per MFMA.  Alone the filter gradients are no faster this way (8.3 vs 8.2 ms per
+  // ResNet-50 step); next to the data-gradient / BatchNorm chain of the main stream, which is where they run, the step
+  // gains 0.8 ms of 37.4 (bench/ab_wide_caps.sh).  DDL_WGRAD_WIDE=0 restores 128 x 128 everywhere.
+  static const int wide_on = [] { const char* e = getenv("DDL_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
+  static const int wide_pad = [] { const char* e = getenv("DDL_WGRAD_WIDE_PAD"); return e ? atoi(e) : 0; }();
+  static const int wide_cap = [] { const char* e = getenv("DDL_WGRAD_WIDE_CAP"); return e ? atoi(e) : 256; }();
+  const int sc_pad = (p.SC + 255) / 256 * 256;
+  const bool wide_fit = K % 128 == 0 && (p.SC % 256 == 0 || (wide_pad && p.SC >= 256 && sc_pad * 100 <= p.SC * 115));
+  if (wide_on && wide_fit && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)
+    return launch_wgrad_wide(p, st, wide_cap);
   if (k64 && n64) return launch_wgrad<64, 64>(p, st);
   if (k64) return launch_wgrad<64, 128>(p, st);
   if (n64) return launch_wgrad<128, 64>(p, st);
