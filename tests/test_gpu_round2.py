@@ -90,6 +90,26 @@ def test_wgrad_over_a_million_rows_matches_fp32():
     _close(out, ref3 + 0.5, rtol=5e-3, atol=5e-3 * ref3.abs().max().item(), what="wgrad 3x3 accumulate, 1.2M rows")
 
 
+@pytest.mark.parametrize("case", [(3, 256, 15, 15, 384, 3, 1, 1), (5, 512, 9, 11, 128, 1, 1, 0), (2, 256, 20, 20, 256, 3, 2, 1)],
+                         ids=["3x3-odd-rows", "1x1-plain", "3x3-stride2"])
+def test_wide_filter_gradient_tiles_accumulate_into_an_existing_gradient(case):
+    """K % 128 == 0 and S*C % 256 == 0 select the 128 x 256 tile (one block per CU, three ring stages, fp32 tile written
+    back in two passes): row counts that are no multiple of the 32-pixel stage, several K tiles, and accumulation INTO a
+    gradient that already holds values (the arena path)."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    N, C, H, W, Kc, R, stride, pad = case
+    assert Kc % 128 == 0 and (R * C) % 256 == 0
+    P, Q = K.conv_out_size(H, R, stride, pad), K.conv_out_size(W, R, stride, pad)
+    x = _rand_act((N, C, H, W), 11)
+    dy = _rand_act((N, Kc, P, Q), 12)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Kc, C, R, R), dy.float(), stride, pad)
+    fresh = K.conv2d_wgrad(dy, x, R, R, stride, pad)
+    _close(fresh, ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item(), what="wide wgrad")
+    held = torch.full((Kc, C, R, R), -0.25, device=_dev()).contiguous(memory_format=CL)
+    out = K.conv2d_wgrad(dy, x, R, R, stride, pad, out=held)
+    _close(out, ref - 0.25, rtol=1e-2, atol=1e-2 * ref.abs().max().item(), what="wide wgrad, accumulated")
+
+
 def test_conv_with_an_operand_beyond_4_gib_takes_the_register_staged_kernel():
     """in_bytes >= 0xFFFF0000: 32-bit buffer offsets of the LDS-DMA ring kernel do not reach, the launcher must fall back
     to conv_igemm (64-bit addressing) and the result must still be right at the far end of the tensor."""
