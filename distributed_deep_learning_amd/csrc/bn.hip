@@ -304,6 +304,80 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_kernel(const bf16_t* 
   }
 }
 
+// The same unit for the 3x3 / stride 2 / pad 1 pool on an even-sized image (ResNet's stem): one thread owns TWO
+// horizontally adjacent pooled outputs of one 8-channel chunk.  Their windows share a column, so 15 instead of 18 input
+// chunks are loaded, all of them issued before the first compare (the generic kernel's run-time loops serialise them).
+// Candidate order (rows outer, columns inner, first maximum wins, NaN propagates) is the generic kernel's.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_321_kernel(const bf16_t* __restrict__ x,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      bf16_t* __restrict__ y, unsigned char* __restrict__ idx,
+                                                                      bf16_t* __restrict__ zmax, unsigned char* __restrict__ pmask,
+                                                                      int N, int H, int W, int C, int P, int Q, long long total) {
+  const int c8 = C >> 3, Q2 = Q >> 1;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+    const int ch = (int)(t % c8);
+    long long r = t / c8;
+    const int b = (int)(r % Q2); r /= Q2;
+    const int p = (int)(r % P);
+    const int n = (int)(r / P);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { sc[e] = scale[ch * 8 + e]; sh[e] = shift[ch * 8 + e]; }
+    const int h0 = 2 * p - 1, w0 = 4 * b - 1;              // rows h0 .. h0+2, columns w0 .. w0+4 (only h0 / w0 can be -1)
+    u32x4 v[3][5];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int h = h0 + i;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const int w = w0 + j;
+        const bool ok = h >= 0 && w >= 0;
+        const size_t off = (((size_t)n * H + (size_t)(ok ? h : 0)) * W + (size_t)(ok ? w : 0)) * C + (size_t)ch * 8;
+        v[i][j] = *reinterpret_cast<const u32x4*>(x + off);
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      float best[8], bz[8];
+      int bi[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bi[e] = 255; bz[e] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        if (h0 + i < 0) continue;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          if (w0 + 2 * o + j < 0) continue;
+          float f[8];
+          unpack8(v[i][2 * o + j], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float a = f[e] * sc[e] + sh[e];
+            if (a > best[e] || a != a) { best[e] = a; bi[e] = i * 3 + j; bz[e] = f[e]; }
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (!(best[e] > 0.f) && best[e] == best[e]) { best[e] = 0.f; bi[e] = 255; }     // ReLU (NaN passes through)
+      const size_t ob = (((size_t)n * P + p) * Q + (size_t)(2 * b + o)) * C + (size_t)ch * 8;
+      *reinterpret_cast<u32x4*>(y + ob) = pack8(best);
+      u32x2 pk;
+      pk[0] = (unsigned)bi[0] | ((unsigned)bi[1] << 8) | ((unsigned)bi[2] << 16) | ((unsigned)bi[3] << 24);
+      pk[1] = (unsigned)bi[4] | ((unsigned)bi[5] << 8) | ((unsigned)bi[6] << 16) | ((unsigned)bi[7] << 24);
+      *reinterpret_cast<u32x2*>(idx + ob) = pk;
+      if (zmax != nullptr) {
+        *reinterpret_cast<u32x4*>(zmax + ob) = pack8(bz);
+        unsigned m = 0u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m |= (bi[e] != 255 ? 1u : 0u) << e;
+        pmask[ob >> 3] = (unsigned char)m;
+      }
+    }
+  }
+}
+
 // gradient of the virtual relu(bn(x)) activation at (row = (n,h,w), 8-channel chunk) from the pooled gradient
 __device__ __forceinline__ void pooled_grad8(const bf16_t* __restrict__ dp, const unsigned char* __restrict__ idx,
                                              const PoolMap& pm, int row, int chunk, int C, float g[8]) {
@@ -1008,6 +1082,13 @@ extern "C" int ddl_bn_relu_maxpool_fwd(const void* x, const float* scale, const 
   if (C % 8 != 0 || k * k > 254 || N <= 0) return -1;
   const PoolMap pm = make_poolmap(H, W, P, Q, k, stride, pad);
   const long long total = (long long)N * P * Q * (C / 8);
+  static const int pair_on = [] { const char* e = getenv("DDL_POOL_FWD_PAIR"); return e ? atoi(e) : 1; }();
+  if (pair_on && k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 4 == 0 && P == H / 2 && Q == W / 2) {
+    hipLaunchKernelGGL(bn_relu_maxpool_fwd_321_kernel, dim3(grid_for(total / 2, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)x, scale, shift, (bf16_t*)y, (unsigned char*)idx, (bf16_t*)zmax, (unsigned char*)pmask,
+                       N, H, W, C, P, Q, total / 2);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(bn_relu_maxpool_fwd_kernel, dim3(grid_for(total, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, scale, shift, (bf16_t*)y, (unsigned char*)idx, (bf16_t*)zmax, (unsigned char*)pmask, pm,
                      N, C, total);

@@ -282,7 +282,8 @@ def test_relu_bwd_bias_grad_fused(shape):
 
 @pytest.mark.parametrize("pooled_sums", [False, True], ids=["gather-sums", "pooled-sums"])
 @pytest.mark.parametrize("shape,pool", [((2, 64, 16, 16), (3, 2, 1)), ((3, 32, 9, 11), (3, 2, 1)), ((2, 16, 8, 8), (2, 2, 0)),
-                                        ((4, 64, 28, 30), (3, 2, 1))])      # even 3/2/1 cases: the 2x2-quad apply kernel
+                                        ((4, 64, 28, 30), (3, 2, 1)),       # even 3/2/1 cases: the 2x2-quad apply kernel
+                                        ((3, 64, 20, 24), (3, 2, 1))])      # W % 4 == 0: the paired forward kernel too
 def test_bn_relu_maxpool_fused_unit(shape, pool, pooled_sums):
     """maxpool(relu(bn(x))) forward + its BN backward from the POOLED gradient vs autograd on fp32 torch ops; the two
     backward sums taken by gathering per full-resolution pixel, or over the pooled tensors (zmax / pmask of the forward)."""
