@@ -317,6 +317,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
     if (!ddl_conv_ring_supported(p)) return -11;
     return ddl_launch_conv_ring(p, MODE, st);
   }
+  if (use_ring && ddl_conv_big_shape(p) != 0) return ddl_launch_conv_big(p, MODE, st);
   if (use_ring && ddl_conv_pring_supported(p)) return ddl_launch_conv_pring(p, MODE, st);
   if (use_ring && !bwd_sums && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
