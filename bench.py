@@ -7,11 +7,19 @@ random-init weights — the metric/config BASELINE.json names.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W               # or under an external launcher
 
+    python bench.py --sweep 1,2,4,8                          # one JSON line per count + scaling efficiency
+
 One rank per GPU over RCCL (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment).  Without a launcher
-environment ``--gpus N`` (N > 1) makes THIS process a launcher: it checks the GPU count without touching HIP, then
-starts N child ranks of this same script on 127.0.0.1 and waits for them (the reference launches its own ranks the
-same way: ``torch.multiprocessing.spawn(process, nprocs=GLOBAL_WORLD)``,
+environment ``--gpus N`` (N > 1) makes THIS process a launcher: it checks the GPU count without touching HIP (sysfs),
+then starts N child ranks of this same script on 127.0.0.1 and waits for them (the reference launches its own ranks
+the same way: ``torch.multiprocessing.spawn(process, nprocs=GLOBAL_WORLD)``,
 ``/root/reference/src/pytorch/CNN/main.py:197-203``).  Too few GPUs is an error, never a silent 1-GPU record.
+``--sweep`` runs the listed counts back to back (the reference compares its modes by epoch time by hand,
+``main.py:80,96``) and reports counts the machine does not have as "not measured".
+
+With several ranks the record also says whether the replicas ended bit-identical (parameter checksums of every rank),
+how long each gradient bucket's collective took on the communicator's stream, and how much of that the compute stream
+actually WAITED for (exposed communication) - taken in three extra steps after the timed region, never inside it.
 
 A step is the full training step: input conversion, forward, loss, backward with bucketed gradient all-reduce
 overlapped on the communicator's stream, fused SGD-momentum update of fp32 masters + bf16 shadow.  W untimed warm-up
@@ -31,7 +39,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # stock PyTorch-ROCm ResNet-50 (bench/stock_models.py) on the same MI355X, img/s per GPU, keyed by per-GPU batch
-STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6794.3}
+STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6794.3}     # + STOCK_EXTRA below (same-session measurements of round 3)
 
 
 def build_parser() -> argparse.ArgumentParser:
@@ -58,6 +66,13 @@ def build_parser() -> argparse.ArgumentParser:
                     help="diagnostic: issue the (identity) RCCL collectives of the DP reducer even on one GPU")
     ap.add_argument("--graph", default="off", choices=["on", "off"],
                     help="replay the whole step as one captured hipGraph (with several ranks: needs --comm native)")
+    ap.add_argument("--sweep", default=None, metavar="N1,N2,...",
+                    help="run the benchmark at each GPU count (e.g. 1,2,4,8) and print one JSON line per count plus a "
+                         "summary line with the scaling efficiency; counts this machine lacks are 'not measured'")
+    ap.add_argument("--comm-proxy", type=int, default=0, metavar="WORKGROUPS",
+                    help="one-GPU diagnostic (with --force-collectives): behind every bucket's identity collective run a "
+                         "streaming kernel of this many workgroups over the bucket on the communicator's stream - what an "
+                         "RCCL ring kernel of that many channels costs the compute streams")
     ap.add_argument("--launch-timeout", type=float, default=1500.0,
                     help="self-launch only: seconds after which the launcher kills its ranks and fails")
     ap.add_argument("--watchdog-s", type=float, default=120.0,
@@ -72,12 +87,12 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
-def self_launch(a, argv) -> int:
-    """``--gpus N`` with no launcher environment: start N ranks of this script.  Nothing here touches the GPU
-    (``device_count`` reads the driver's device list without creating a HIP context), the children are fresh
+def self_launch(a, argv, capture=None) -> int:
+    """``--gpus N`` with no launcher environment: start N ranks of this script.  Nothing here touches the GPU (the
+    count comes from the KFD topology in sysfs; without it a throw-away child is asked), the children are fresh
     processes — never an exec of a process that already initialised HIP."""
-    import torch
-    have = torch.cuda.device_count()
+    from distributed_deep_learning_amd.utils.host import visible_gpus
+    have = visible_gpus()
     if have < a.gpus:
         print(f"bench.py: --gpus {a.gpus} needs {a.gpus} GPUs, this machine shows {have} - refusing to report a "
               f"{have}-GPU number as an {a.gpus}-GPU one", file=sys.stderr, flush=True)
@@ -87,7 +102,8 @@ def self_launch(a, argv) -> int:
     for r in range(a.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DDL_BENCH_SELF_LAUNCHED="1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+        out = capture if (capture is not None and r == 0) else None
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out))
     deadline = time.monotonic() + a.launch_timeout
     rc = 0
     live = set(range(a.gpus))
@@ -119,6 +135,63 @@ def self_launch(a, argv) -> int:
     return rc
 
 
+def run_sweep(a, argv) -> int:
+    """One benchmark run per GPU count, each in fresh processes; efficiency = value(N) / (N * value(smallest count))."""
+    import tempfile
+    from distributed_deep_learning_amd.utils.host import visible_gpus
+    counts = [int(v) for v in a.sweep.split(",") if v.strip()]
+    have = visible_gpus()
+    base_argv = []
+    skip = False
+    for tok in argv:                                   # everything but --sweep / --gpus and their values
+        if skip:
+            skip = False
+            continue
+        if tok in ("--sweep", "--gpus"):
+            skip = True
+            continue
+        if tok.startswith("--sweep=") or tok.startswith("--gpus="):
+            continue
+        base_argv.append(tok)
+    results = {}
+    rc_all = 0
+    for n in counts:
+        if n > have:
+            rec = {"n_gpus": n, "status": "not measured", "reason": f"this machine shows {have} GPU(s)"}
+            print(json.dumps(rec), flush=True)
+            results[n] = None
+            continue
+        sub = build_parser().parse_args(["--gpus", str(n), *base_argv])
+        with tempfile.TemporaryFile(mode="w+") as out:
+            if n == 1:
+                env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+                rc = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", *base_argv], env=env,
+                                    stdout=out).returncode
+            else:
+                rc = self_launch(sub, ["--gpus", str(n), *base_argv], capture=out)
+            out.seek(0)
+            lines = [ln for ln in out.read().splitlines() if ln.startswith("{")]
+        if rc != 0 or not lines:
+            rc_all = rc_all or rc or 1
+            print(json.dumps({"n_gpus": n, "status": "failed", "returncode": rc}), flush=True)
+            results[n] = None
+            continue
+        print(lines[-1], flush=True)
+        results[n] = json.loads(lines[-1])
+    done = [n for n in counts if results.get(n)]
+    summary = {"sweep": counts, "metric": "scaling efficiency = value(N) / (N/N0 * value(N0)), weak scaling",
+               "measured": done, "not_measured": [n for n in counts if not results.get(n)]}
+    if done:
+        n0 = done[0]
+        v0 = results[n0]["value"]
+        summary["baseline_gpus"] = n0
+        summary["images_per_sec"] = {str(n): results[n]["value"] for n in done}
+        summary["efficiency"] = {str(n): round(results[n]["value"] / (v0 * n / n0), 4) for n in done}
+        summary["replicas_identical"] = {str(n): results[n].get("replicas_identical") for n in done}
+    print(json.dumps(summary), flush=True)
+    return rc_all
+
+
 # ----------------------------------------------------------------------------------------------- one rank
 def run_rank(a) -> int:
     import torch
@@ -142,7 +215,8 @@ def run_rank(a) -> int:
               file=sys.stderr)
         return 2
     dev = torch.device(f"cuda:{info.local_rank}")
-    ddist.init(info, dev, force=a.force_collectives)
+    # control plane: gloo beside the native communicator (no RCCL communicator inside c10d), nccl for --comm torch
+    ddist.init(info, dev, force=a.force_collectives, comm=a.comm)
     torch.manual_seed(1234)
 
     classes = 10 if a.model == "resnet18_cifar" else 1000
@@ -156,6 +230,8 @@ def run_rank(a) -> int:
                                       watchdog_s=a.watchdog_s)
         arena = ddp.arena
         comm_note = ddp.comm_note
+        if a.comm_proxy > 0 and ddp.ncomm is not None and info.world == 1:
+            ddp.ncomm.proxy_workgroups = a.comm_proxy
     else:
         arena = ParamArena(model.named_parameters(), bucket_bytes=int(a.bucket_mb * 2**20))
     if a.optimizer == "lars":
@@ -189,6 +265,9 @@ def run_rank(a) -> int:
             return graphed(x, y)
 
     def fence():
+        # every rank's GPU work is done when the barrier opens (the control plane may be a CPU-side gloo barrier), then
+        # synchronize once more so nothing enqueued by the barrier itself is left
+        torch.cuda.synchronize()
         if info.world > 1:
             td.barrier()
         torch.cuda.synchronize()
@@ -211,13 +290,39 @@ def run_rank(a) -> int:
     ms1 = torch.cuda.memory_stats(dev)
     alloc_diag = {k: int(ms1.get(k, 0) - ms0.get(k, 0)) for k in ("num_device_alloc", "num_device_free", "num_alloc_retries")}
     alloc_diag["reserved_gib"] = round(ms1.get("reserved_bytes.all.current", 0) / 2**30, 2)
-    tmax = torch.tensor([dt_local], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt_local], dtype=torch.float64)
     tmin = tmax.clone()
     if info.world > 1:
-        td.all_reduce(tmax, op=td.ReduceOp.MAX)
-        td.all_reduce(tmin, op=td.ReduceOp.MIN)
+        ddist.all_reduce_any(tmax, op=td.ReduceOp.MAX)
+        ddist.all_reduce_any(tmin, op=td.ReduceOp.MIN)
     dt = float(tmax.item())
     final_loss = float(loss.detach().float().item())
+
+    # ---- after the timed region: replica check and communication diagnostics (three extra eager steps)
+    replicas_identical = None
+    comm_diag = None
+    if ddp is not None and ddp.dist:
+        cs = ddp.param_checksum()
+        replicas_identical = bool(torch.equal(cs, cs[0:1].expand_as(cs)))
+        if not graph_on:
+            ddp.profile_sync = True
+            if ddp.ncomm is not None:
+                ddp.ncomm.start_profile()
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            exposed = sorted(t0.elapsed_time(t1) for t0, t1 in ddp.sync_wait_events)
+            per_bucket = {}
+            if ddp.ncomm is not None:
+                for tag, ms in ddp.ncomm.stop_profile():
+                    if isinstance(tag, tuple) and tag[0] == "bucket":
+                        per_bucket.setdefault(int(tag[1]), []).append(ms)
+            comm_diag = {"exposed_comm_ms_per_step_median": round(exposed[len(exposed) // 2], 3) if exposed else None,
+                         "bucket_collective_ms_median": {str(b): round(sorted(v)[len(v) // 2], 3)
+                                                         for b, v in sorted(per_bucket.items())},
+                         "note": "rank 0's view; collective time on the communicator's stream includes waiting for peers"}
+            cs = ddp.param_checksum()
+            replicas_identical = replicas_identical and bool(torch.equal(cs, cs[0:1].expand_as(cs)))
 
     if info.rank == 0:
         gb = a.batch * info.world
@@ -233,6 +338,10 @@ def run_rank(a) -> int:
                        "parallelism": f"dp{info.world}", "sync": a.sync, "optimizer": a.optimizer,
                        "bucket_mb": a.bucket_mb, "grad_wire_dtype": a.grad_dtype, "comm": comm_used, "hip_graph": graph_on},
             "rccl_ranks": (ddp.comm_ranks() if ddp is not None and ddp.dist else 1),
+            "replicas_identical": replicas_identical,
+            "comm_diagnostics": comm_diag,
+            "control_plane": (td.get_backend() if td.is_initialized() else "none"),
+            "comm_proxy_workgroups": a.comm_proxy or None,
             "ms_per_step_rank_min": round(1e3 * float(tmin.item()) / a.steps, 3),
             "ms_per_step_rank_max": round(1e3 * dt / a.steps, 3),
             "gpu_step_ms_min_median_max": [round(step_ms[0], 3), round(step_ms[len(step_ms) // 2], 3), round(step_ms[-1], 3)],
@@ -260,6 +369,11 @@ def main(argv=None) -> int:
         return 2
     from distributed_deep_learning_amd import dist as ddist
     info = ddist.discover()
+    if a.sweep:
+        if info.launcher != "none":
+            print("bench.py: --sweep starts its own ranks; run it without a launcher", file=sys.stderr)
+            return 2
+        return run_sweep(a, argv)
     if info.world == 1 and a.gpus > 1 and info.launcher == "none":
         return self_launch(a, argv)
     return run_rank(a)

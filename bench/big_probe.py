@@ -42,6 +42,8 @@ CASES = [
 PARITY = [(64, 45, 192, 1, 1, 0, "fa"), (96, 33, 320, 3, 1, 1, "fa"), (128, 47, 512, 3, 2, 1, "fa"), (64, 45, 256, 1, 1, 0, "fa"),
           (256, 21, 256, 3, 1, 1, "fa"), (32, 19, 128, 1, 1, 0, "fa"), (128, 33, 320, 3, 1, 1, "fa"), (192, 25, 1024, 1, 1, 0, "fa"),
           (320, 33, 128, 1, 1, 0, "da"), (320, 33, 128, 3, 1, 1, "d"), (1024, 25, 192, 1, 1, 0, "d"),
+          # 530 tiles = 2 rounds + 18: the launcher cuts the batch (64 images big-tile, 3 images ring kernels)
+          (128, 45, 256, 3, 1, 1, "fa"), (256, 45, 128, 3, 1, 1, "d"), (256, 45, 128, 1, 1, 0, "da"),
           (192, 45, 64, 1, 1, 0, "da"), (320, 33, 96, 1, 1, 0, "da"), (256, 45, 64, 1, 1, 0, "dn"), (320, 33, 96, 3, 1, 1, "d"),
           (256, 21, 256, 3, 1, 1, "d")]
 
@@ -149,7 +151,7 @@ def main():
     settings = [("base", {"DDL_CONV_BIG": "0"}), ("big", {"DDL_CONV_BIG": "2"}), ("base", {"DDL_CONV_BIG": "0"}),
                 ("big", {"DDL_CONV_BIG": "2"})]
     if what == "parity":
-        settings = settings[1:2]
+        settings = [("big-everything", {"DDL_CONV_BIG": "2"}), ("big-default", {"DDL_CONV_BIG": "1"})]
     rows = []
     for name, e in settings:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(B), what, "child"], env=dict(os.environ, **e),

@@ -440,13 +440,35 @@ static bool big_can_run(const ConvParams& p) {
 }
 
 // 0 = the layer goes elsewhere; 1 = 256 pixels x 256 channels.
-// DDL_CONV_BIG: 0 never, 1 (default) where it measures faster than the ring kernels, 2 everything it can run.
+// DDL_CONV_BIG: 0 never; 1 (default) the FORWARD convolutions it measures faster on (bench/big_probe.py,
+// profiles/r3_big_tile_vs_ring_b*.txt: reductions of at least 1024 - the 3x3 layers from 128 channels on and the 1x1
+// layers from 1024 input channels on; 0.80-0.90 of the ring kernel's time on whole tile rounds); 2 everything it can
+// run; 3 = 1; 4 data gradients only; 5 forward and data gradients.  The data gradients are 0.80-0.87 in isolation too but
+// LOSE inside the step (+0.5 % step time, bench/r3_ab_big.sh): a 146 KiB one-block-per-CU kernel leaves no room for the
+// filter-gradient blocks that run beside the data gradient on the side stream, so the two serialise.
 int ddl_conv_big_shape(const ConvParams& p) {
   static const int enabled = [] { const char* e = getenv("DDL_CONV_BIG"); return e ? atoi(e) : 1; }();
   if (!enabled || !big_can_run(p)) return 0;
-  if (enabled >= 2) return 1;
+  if (enabled == 2) return 1;
+  if ((enabled == 1 || enabled == 3) && p.mode_hint != 0) return 0;
+  if (enabled == 4 && p.mode_hint != 1) return 0;
   const long long tiles = (long long)((p.M + GBM - 1) / GBM) * ((p.OC + GBN - 1) / GBN);
-  return (p.Kred >= 512 && tiles >= 512 && p.OC % GBN == 0) ? 1 : 0;
+  return (p.Kred >= 1024 && p.OC % GBN == 0 && p.addend == nullptr && tiles >= 180) ? 1 : 0;
+}
+
+// Tile rounds: 256 persistent blocks take whole tiles, so R + f rounds of tiles cost R + 1 rounds of time.  When the
+// last round would be less than 60 % full the launcher cuts the batch at an image boundary: the images that make R
+// whole rounds run here, the rest goes to the ring kernels (two 256 x 128 blocks per CU: finer tiles for the tail).
+// Returns the number of leading images for this kernel (N: everything, no split).
+int ddl_conv_big_split(const ConvParams& p) {
+  static const int split_on = [] { const char* e = getenv("DDL_BIG_SPLIT"); return e ? atoi(e) : 1; }();
+  const long long tiles_n = (p.OC + GBN - 1) / GBN, pix = (long long)p.OH * p.OW;
+  const long long tiles = (long long)((p.M + GBM - 1) / GBM) * tiles_n;
+  const long long R = tiles / 256, f = tiles - R * 256;
+  if (!split_on || R == 0 || f == 0 || f >= 154 || p.out_ld != p.OC) return p.N;
+  const long long n0 = (R * 256 / tiles_n) * GBM / pix;            // images whose tiles fit in R rounds
+  if (n0 <= 0 || n0 >= p.N) return p.N;
+  return (int)n0;
 }
 
 int ddl_launch_conv_big(ConvParams& p, int mode, hipStream_t stream) {

@@ -317,7 +317,27 @@ static int launch_any(ConvParams& p, hipStream_t st) {
     if (!ddl_conv_ring_supported(p)) return -11;
     return ddl_launch_conv_ring(p, MODE, st);
   }
-  if (use_ring && ddl_conv_big_shape(p) != 0) return ddl_launch_conv_big(p, MODE, st);
+  if (use_ring && ddl_conv_big_shape(p) != 0) {
+    const int n0 = ddl_conv_big_split(p);
+    if (n0 >= p.N) return ddl_launch_conv_big(p, MODE, st);
+    // whole tile rounds on the big-tile kernel, the remaining images on the ring kernels (conv_big.hip)
+    ConvParams a = p;
+    a.N = n0; a.M = n0 * p.OH * p.OW;
+    a.in_bytes = 2ull * (unsigned long long)n0 * p.IH * p.IW * p.IC;
+    const int rc = ddl_launch_conv_big(a, MODE, st);
+    if (rc != 0) return rc;
+    ConvParams b = p;
+    const size_t opix = (size_t)n0 * p.OH * p.OW;
+    b.N = p.N - n0; b.M = b.N * p.OH * p.OW;
+    b.in = p.in + (size_t)n0 * p.IH * p.IW * p.IC;
+    b.in_bytes = 2ull * (unsigned long long)b.N * p.IH * p.IW * p.IC;
+    b.out = p.out + opix * (size_t)p.out_ld;
+    if (p.addend != nullptr) b.addend = p.addend + opix * (size_t)p.OC;
+    if (p.addend_mask != nullptr) b.addend_mask = p.addend_mask + opix * (size_t)(p.OC >> 3);
+    if (ddl_conv_pring_supported(b)) return ddl_launch_conv_pring(b, MODE, st);
+    if (ddl_conv_ring_supported(b)) return ddl_launch_conv_ring(b, MODE, st);
+    return ddl_launch_conv_big(b, MODE, st);
+  }
   if (use_ring && ddl_conv_pring_supported(p)) return ddl_launch_conv_pring(p, MODE, st);
   if (use_ring && !bwd_sums && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);

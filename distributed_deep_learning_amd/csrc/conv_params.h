@@ -69,6 +69,7 @@ int ddl_launch_conv_pring(ConvParams& p, int mode, hipStream_t stream);
 
 // conv_big.hip (256 x 256 / 512 x 128 block tiles, two wave groups half a K-step apart, persistent: the MFMA-bound layers)
 int ddl_conv_big_shape(const ConvParams& p);
+int ddl_conv_big_split(const ConvParams& p);
 int ddl_launch_conv_big(ConvParams& p, int mode, hipStream_t stream);
 
 // conv_patch.hip (3x3 / stride 1 / pad 1 with an LDS-resident input patch)

@@ -355,6 +355,28 @@ extern "C" int ddl_spin(long long microseconds, void* stream) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- stand-in for a ring collective's kernel (diagnostics)
+// What an RCCL ring all-reduce does to the GPU that hosts it: a FEW workgroups (one per channel) that stream the bucket
+// through registers - read, combine, write - for the whole duration of the transfer, on the communicator's stream, beside
+// the compute kernels.  On one GPU the real collective is an identity; this kernel reproduces its footprint (workgroups,
+// bytes read + written, `passes` sweeps ~ the 2 (N-1)/N traversals of a ring) so that bench.py --comm-proxy can measure
+// what that many resident workgroups cost the compute streams.  Values are written back unchanged.
+__global__ __launch_bounds__(256) void stream_proxy_kernel(u32x4* __restrict__ p, long long n16, int passes) {
+  for (int ps = 0; ps < passes; ++ps)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+      u32x4 v = p[i];
+      asm volatile("" : "+v"(v));              // keep the load and the store: the data goes through registers
+      p[i] = v;
+    }
+}
+extern "C" int ddl_stream_proxy(void* buf, long long bytes, int workgroups, int passes, void* stream) {
+  if (workgroups < 1 || workgroups > 1024 || passes < 1 || passes > 16 || bytes < 0 || ((uintptr_t)buf & 15) != 0) return -1;
+  const long long n16 = bytes / 16;
+  if (n16 == 0) return 0;
+  hipLaunchKernelGGL(stream_proxy_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (u32x4*)buf, n16, passes);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- channel windows of NHWC buffers
 // dst[row][0..C) = src[row][0..C) for two [M][*] bf16 buffers with independent row pitches (elements): packs a dense
 // tensor into a channel window of a wider buffer (dense-block feature map) or extracts a window into a dense tensor.

@@ -1,5 +1,13 @@
-"""Process-group bootstrap and rank discovery: one process per GPU, ``torch.distributed`` over RCCL (the
-``"nccl"`` backend on ROCm) for GPU tensors and gloo for CPU tensors.
+"""Process-group bootstrap and rank discovery: one process per GPU.
+
+Two planes.  The CONTROL plane is a ``torch.distributed`` process group: rendezvous, the 128-byte RCCL id, barriers,
+metric and checksum reductions of a few bytes.  The DATA plane moves gradients and parameters: on GPUs the native RCCL
+communicator (``parallel/native_comm.py``, one per device that holds parameters), on CPUs gloo.  With the native data
+plane the control plane is GLOO even on GPUs: no second RCCL communicator inside c10d (double buffers, double init
+time, one more tenant of the four hardware queues), and no process group bound to ONE device - which is what makes
+data-parallel x model-parallel work, where a rank drives several GPUs and every stage has its own communicator
+(``/root/reference/src/pytorch/CNN/main.py:134-154``).  ``backend="nccl"`` keeps everything inside ``torch.distributed``
+(``--comm torch``).
 
 Rank discovery honours, in order: explicit arguments, torchrun (``RANK/WORLD_SIZE/LOCAL_RANK``), Open MPI
 (``OMPI_COMM_WORLD_*`` — what the reference reads at ``/root/reference/src/pytorch/CNN/main.py:62-67``), SLURM.
@@ -44,14 +52,19 @@ def discover(env=None) -> RankInfo:
     return RankInfo()
 
 
-def backend_for(device: torch.device) -> str:
-    return "nccl" if device.type == "cuda" else "gloo"
+def backend_for(device: torch.device, comm: str = "native") -> str:
+    """Control-plane backend: gloo on CPUs and beside the native RCCL data plane, nccl (= RCCL inside c10d) for
+    ``comm="torch"`` on GPUs."""
+    return "nccl" if (device.type == "cuda" and comm == "torch") else "gloo"
 
 
 def init(info: Optional[RankInfo] = None, device: Optional[torch.device] = None, timeout_s: float = 600.0,
-         master_addr: Optional[str] = None, master_port: Optional[int] = None, force: bool = False) -> RankInfo:
-    """Initialise the default process group (no-op for world == 1).  Binds ``cuda:{local_rank}`` first so RCCL
-    opens its communicator on the right GPU (the reference leaves every non-``data`` rank on ``cuda:0``)."""
+         master_addr: Optional[str] = None, master_port: Optional[int] = None, force: bool = False,
+         comm: str = "native", bind_device: bool = True) -> RankInfo:
+    """Initialise the default process group (no-op for world == 1).  Makes ``device`` the current device first so every
+    RCCL communicator opens on the right GPU (the reference leaves every non-``data`` rank on ``cuda:0``).
+    ``comm``: data plane on GPUs (see the module doc).  ``bind_device=False``: an nccl group that is not tied to one
+    device (a rank that drives several GPUs: model / pipeline stages)."""
     info = info or discover()
     if device is not None and device.type == "cuda":
         torch.cuda.set_device(device)
@@ -64,9 +77,9 @@ def init(info: Optional[RankInfo] = None, device: Optional[torch.device] = None,
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    backend = backend_for(device or torch.device("cpu"))
+    backend = backend_for(device or torch.device("cpu"), comm)
     kwargs = {}
-    if backend == "nccl" and device is not None:
+    if backend == "nccl" and device is not None and bind_device:
         kwargs["device_id"] = device
     td.init_process_group(backend=backend, rank=info.rank, world_size=info.world,
                           timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
@@ -98,12 +111,44 @@ def shutdown() -> None:
             td.destroy_process_group()
 
 
+def control_device(group=None, fallback: Optional[torch.device] = None) -> torch.device:
+    """Where a tensor must live to go through the control plane: CPU for gloo; for nccl the device the group is bound
+    to, else ``fallback`` (an unbound nccl group takes tensors of any device)."""
+    if not (td.is_available() and td.is_initialized()) or td.get_backend(group) != "nccl":
+        return torch.device("cpu")
+    pg = group if group is not None else td.distributed_c10d._get_default_group()   # noqa: SLF001
+    bound = getattr(pg, "bound_device_id", None)
+    if bound is not None:
+        return torch.device(bound)
+    return fallback if fallback is not None and fallback.type == "cuda" else torch.device("cuda", torch.cuda.current_device())
+
+
+def all_reduce_any(t: torch.Tensor, op=None, group=None) -> torch.Tensor:
+    """Small all-reduce of a tensor on ANY device through the control plane (metrics, flags, checksums): staged
+    through the control plane's device when the tensor lives elsewhere.  In place; returns ``t``."""
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size(group) <= 1:
+        return t
+    op = td.ReduceOp.SUM if op is None else op
+    dev = control_device(group, t.device)
+    if dev == t.device:
+        td.all_reduce(t, op=op, group=group)
+    else:
+        h = t.detach().to(dev)
+        td.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    return t
+
+
 def broadcast_flat(t: torch.Tensor, src: int = 0) -> None:
     if is_dist():
-        td.broadcast(t, src)
+        dev = control_device(None, t.device)
+        if dev == t.device:
+            td.broadcast(t, src)
+        else:
+            h = t.detach().to(dev)
+            td.broadcast(h, src)
+            t.copy_(h)
 
 
 def all_reduce_sum(t: torch.Tensor) -> torch.Tensor:
-    if is_dist():
-        td.all_reduce(t, op=td.ReduceOp.SUM)
-    return t
+    return all_reduce_any(t)

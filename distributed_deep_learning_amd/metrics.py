@@ -57,8 +57,8 @@ class PhaseMeter:
         """-> (accuracy %, mean loss, samples, seconds).  One host sync."""
         a = self.acc.clone()
         if reduce and td.is_available() and td.is_initialized() and td.get_world_size() > 1:
-            a = a.float() if a.device.type == "cuda" else a
-            td.all_reduce(a)
+            from .dist import all_reduce_any
+            all_reduce_any(a)                  # three doubles through the control plane (CPU-staged beside native RCCL)
         loss_n, correct, n = (float(v) for v in a.tolist())
         dt = time.perf_counter() - self.t0
         n = max(n, 1.0)

@@ -28,6 +28,7 @@ _SIGS = {
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_spin": [_ll, _vp],
+    "ddl_stream_proxy": [_vp, _ll, C.c_int, C.c_int, _vp],
     "ddl_bn_slots": [],
     "ddl_slab_fold": [_vp, _i, _vp, _i, _vp],
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],

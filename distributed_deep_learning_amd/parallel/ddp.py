@@ -16,9 +16,11 @@ can never deadlock on mismatched call order even if autograd visits parameters d
 
 Transports (one reducer, three ways to move a bucket):
 
-* GPU, ``comm="native"`` (default): direct RCCL calls from ``csrc/comm.cpp`` on a stream the communicator owns;
-  checked once against ``torch.distributed`` at start-up (all ranks agree to fall back together if it disagrees);
-* GPU, ``comm="torch"``: ``torch.distributed`` (backend ``nccl`` = RCCL);
+* GPU, ``comm="native"`` (default): direct RCCL calls from ``csrc/comm.cpp`` on a stream the communicator owns, one
+  communicator per reducer (= per device that holds parameters); ``torch.distributed`` is only the control plane
+  (gloo by default, see ``dist.py``).  One averaged all-reduce is checked against its closed-form result at start-up
+  and all ranks agree to fall back together if any of them disagrees;
+* GPU, ``comm="torch"``: ``torch.distributed`` (backend ``nccl`` = RCCL inside c10d);
 * gloo: CPU tensors directly; GPU tensors are staged through pinned host memory BY THIS MODULE (gloo's own
   GPU path runs its copies on high-priority streams that wait on events of normal-priority streams — the pattern
   behind the two GPU-side deadlocks recorded in ``docs/STATUS.md``; the staging here uses only the current stream).
@@ -58,7 +60,9 @@ class ReducerWatchdog:
     c10d work's ``is_completed``).  A daemon thread retires finished entries in order; the oldest unfinished one
     older than ``timeout_s`` triggers ``report(tag, age)`` (text for stderr) and ``os._exit(exit_code)``."""
 
-    def __init__(self, timeout_s: float, report, exit_code: int = 3, on_timeout=None):
+    def __init__(self, timeout_s: float, report, exit_code: int = 3, on_timeout=None, device=None):
+        self.device = device                    # the probes are HIP event queries: the thread must sit on THEIR device
+        self.probe_errors = 0
         self.timeout_s = float(timeout_s)
         self.report = report
         self.exit_code = exit_code
@@ -81,14 +85,24 @@ class ReducerWatchdog:
             self._thread = threading.Thread(target=self._run, name="ddl-reducer-watchdog", daemon=True)
             self._thread.start()
 
-    @staticmethod
-    def _safe(probe) -> bool:
+    def _safe(self, probe) -> bool:
+        """True = retire the entry.  A probe that RAISES tells nothing about the collective: it is logged once and the
+        entry is dropped as unobservable - never counted as pending (a healthy job must not be killed by its watchdog)."""
         try:
             return bool(probe())
-        except Exception:                       # noqa: BLE001 - a failing probe must not kill the watchdog
-            return False
+        except Exception as e:                  # noqa: BLE001 - a failing probe must not kill the watchdog
+            self.probe_errors += 1
+            if self.probe_errors == 1:
+                print(f"[ddl reducer watchdog] probe failed ({e!r}); entry dropped as unobservable", file=sys.stderr,
+                      flush=True)
+            return True
 
     def _run(self) -> None:
+        if self.device is not None and getattr(self.device, "type", None) == "cuda":
+            try:
+                torch.cuda.set_device(self.device)          # a new thread starts on device 0 on every rank
+            except Exception:                   # noqa: BLE001
+                pass
         poll = min(1.0, max(0.02, self.timeout_s / 20.0))
         while not self._stop.wait(poll):
             with self._lock:
@@ -172,22 +186,24 @@ class DistributedDataParallel(tnn.Module):
         self.arena = arena
         self.backend = td.get_backend(self.pg) if self.dist else "none"
         self.on_gpu = arena.device.type == "cuda"
-        # gloo over GPU tensors: host staging (see module doc); DDL_GLOO_GPU_DIRECT=1 hands the GPU tensors to gloo itself
-        # (the configuration that hung in round 1 - kept for bench/ddp_gloo_gpu.py --transport gloo-gpu)
-        self.staged = self.backend == "gloo" and self.on_gpu and os.environ.get("DDL_GLOO_GPU_DIRECT", "0") != "1"
+        # gloo over GPU tensors: always host-staged (see module doc; handing GPU tensors to gloo is the configuration that
+        # hung in round 1 and is not reachable any more)
+        self.staged = self.backend == "gloo" and self.on_gpu
         if grad_dtype not in (None, torch.float32, torch.bfloat16):
             raise ValueError("grad_dtype must be None / torch.float32 (in place) or torch.bfloat16")
         self.grad_dtype = torch.bfloat16 if grad_dtype == torch.bfloat16 else None
         self._comm_bufs: dict = {}
         if comm is None:
-            comm = "native" if (self.on_gpu and self.backend == "nccl") else "torch"
+            comm = "native" if self.on_gpu else "torch"
+        if comm == "native" and not self.on_gpu:
+            comm = "torch"                      # CPU tensors: gloo through torch.distributed
         if comm not in ("torch", "native"):
             raise ValueError("comm must be 'torch' or 'native'")
         self.ncomm = None
         self.comm_note: Optional[str] = None
+        self.profile_sync = False               # diagnostics: time the main stream's wait for the collectives per step
+        self.sync_wait_events: List = []
         if comm == "native" and self.dist:
-            if not self.on_gpu:
-                raise ValueError("comm='native' drives RCCL directly: GPU tensors only")
             self._open_native()
         self.broadcast_buffers = broadcast_buffers
         self._handles: List = []
@@ -203,7 +219,7 @@ class DistributedDataParallel(tnn.Module):
         self.require_sync = True
         if watchdog_s is None:
             watchdog_s = float(os.environ.get("DDL_REDUCER_WATCHDOG_S", "300"))
-        self.watchdog = ReducerWatchdog(watchdog_s, self._hang_report) if self.dist else None
+        self.watchdog = ReducerWatchdog(watchdog_s, self._hang_report, device=arena.device) if self.dist else None
         self.sync_parameters()
         self._hooks = []
         if self.dist:
@@ -214,25 +230,26 @@ class DistributedDataParallel(tnn.Module):
 
     # ------------------------------------------------------------------ transports
     def _open_native(self) -> None:
-        """Create the native communicator and compare one averaged all-reduce with ``torch.distributed``'s; every rank
-        learns the verdict of all ranks, so a failed check moves the WHOLE job to ``comm='torch'``."""
+        """Create the native communicator on THIS reducer's device and check one averaged all-reduce against its closed
+        form (rank r contributes ``i * (r + 1) + 0.25``: the mean is ``i * (world + 1) / 2 + 0.25``); every rank learns
+        the verdict of all ranks through the control plane, so a failed check moves the WHOLE job to
+        ``torch.distributed``.  Nothing here hands a tensor of this device to a process group bound to another one."""
+        from ..dist import all_reduce_any
         from .native_comm import NativeCommunicator
         ok = 1.0
         try:
             self.ncomm = NativeCommunicator(self.rank, self.world, self.arena.device, group=self.pg)
-            t = torch.arange(4096, dtype=torch.float32, device=self.arena.device) * float(self.rank + 1) + 0.25
-            ref = t.clone()
+            base = torch.arange(4096, dtype=torch.float32, device=self.arena.device)
+            t = base * float(self.rank + 1) + 0.25
             self.ncomm.all_reduce(t, average=True).wait()
-            td.all_reduce(ref, op=td.ReduceOp.AVG if self.backend == "nccl" else td.ReduceOp.SUM, group=self.pg)
-            if self.backend != "nccl":
-                ref /= self.world
+            ref = base * (0.5 * (self.world + 1)) + 0.25
             if not torch.allclose(t, ref, rtol=1e-6, atol=1e-6) or self.ncomm.ranks() != self.world:
                 ok = 0.0
         except Exception as e:                  # noqa: BLE001 - any failure of the optional transport means fallback
             ok = 0.0
             self.comm_note = f"native communicator unavailable on rank {self.rank}: {e!r}"
-        flag = torch.tensor([ok], device=self.arena.device if self.backend == "nccl" else "cpu")
-        td.all_reduce(flag, op=td.ReduceOp.MIN, group=self.pg)
+        flag = torch.tensor([ok])
+        all_reduce_any(flag, op=td.ReduceOp.MIN, group=self.pg)
         if float(flag.item()) < 1.0:
             if self.ncomm is not None:
                 self.ncomm.close()
@@ -268,12 +285,16 @@ class DistributedDataParallel(tnn.Module):
     def _broadcast(self, t: torch.Tensor, src: int = 0) -> None:
         if self.ncomm is not None and t.dtype in (torch.float32, torch.bfloat16) and t.is_contiguous() and t.numel() > 0:
             self.ncomm.broadcast(t, src).wait()
-        elif self.staged and t.is_cuda:
-            host = t.detach().cpu()
+        elif t.is_cuda and (self.staged or self._control_device(t) != t.device):
+            host = t.detach().to(self._control_device(t))
             td.broadcast(host, src, group=self.pg)
             t.copy_(host)
         else:
             td.broadcast(t, src, group=self.pg)
+
+    def _control_device(self, t: torch.Tensor) -> torch.device:
+        from ..dist import control_device
+        return control_device(self.pg, t.device)
 
     # ------------------------------------------------------------------ setup
     def sync_parameters(self) -> None:
@@ -364,7 +385,7 @@ class DistributedDataParallel(tnn.Module):
         inv = 1.0 / self.world
         src = g if self.grad_dtype is None else self._pack(b, g)
         if self.ncomm is not None:
-            h, scale = self.ncomm.all_reduce(src, average=True), False
+            h, scale = self.ncomm.all_reduce(src, average=True, tag=("bucket", b)), False
         elif self.backend == "nccl":
             h, scale = td.all_reduce(src, op=td.ReduceOp.AVG, group=self.pg, async_op=True), False
         else:
@@ -402,9 +423,19 @@ class DistributedDataParallel(tnn.Module):
             self._pending[b] = 0
         self._drain()
         with device_of(self.arena.device):
+            t0 = None
+            if self.profile_sync and self.on_gpu and not torch.cuda.is_current_stream_capturing():
+                # exposed communication = how long the compute stream sits in these waits: both events go on the COMPUTE
+                # stream, the first in front of the first wait, the second behind the last
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(torch.cuda.current_stream(self.arena.device))
             for b, h, finish in self._handles:
                 self._wait(b, h)
                 finish()
+            if t0 is not None:
+                t1 = torch.cuda.Event(enable_timing=True)
+                t1.record(torch.cuda.current_stream(self.arena.device))
+                self.sync_wait_events.append((t0, t1))
             self._note_step()
         self._handles = []
         self._armed = False
@@ -504,8 +535,7 @@ class DistributedDataParallel(tnn.Module):
         local = torch.stack([a.sum(), (a * a).sum()])
         if not self.dist:
             return local.unsqueeze(0)
-        if self.staged:
-            local = local.cpu()
+        local = local.to(self._control_device(local))         # two doubles: through the control plane
         out = [torch.zeros_like(local) for _ in range(self.world)]
         td.all_gather(out, local, group=self.pg)
         return torch.stack(out).to(self.arena.device)

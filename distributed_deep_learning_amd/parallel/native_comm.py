@@ -3,8 +3,9 @@ communicator owns, next to — not through — ``torch.distributed``.
 
 Why: one ctypes call per collective instead of a c10d work object, a communication stream whose ordering against
 the compute streams is explicit (events), and calls that are plain stream operations (capturable in a hipGraph).
-``torch.distributed`` stays the bootstrap: the 128-byte RCCL unique id travels through the default process group
-(any backend) or a ``TCPStore``.  RCCL itself is the copy torch ships (``torch/lib/librccl.so``), resolved with
+``torch.distributed`` stays the bootstrap (the control plane of ``dist.py``): the 128-byte RCCL unique id travels
+through the default process group - on its CONTROL device, so a gloo group never sees a GPU tensor and a device-bound nccl
+group never sees a foreign device - or through a ``TCPStore``.  RCCL itself is the copy torch ships (``torch/lib/librccl.so``), resolved with
 ``dlopen`` so the process never maps two RCCLs.
 
 Default transport of the GPU reducer (``DistributedDataParallel(comm="native")`` / ``--comm native``); the reducer
@@ -53,6 +54,8 @@ class _Handle:
 
 
 class NativeCommunicator:
+    _store_seq = 0
+
     def __init__(self, rank: int, world: int, device: torch.device, group=None, store=None):
         """Collective constructor (every rank calls it).  The unique id is broadcast through ``group`` (a
         ``torch.distributed`` group, default: the default group when initialised) or exchanged through ``store``
@@ -60,6 +63,9 @@ class NativeCommunicator:
         self.lib = _lib.require()
         check(self.lib.ddl_comm_load(_rccl_path()), "ddl_comm_load (RCCL not found)")
         self.rank, self.world, self.device = rank, world, device
+        self.profile = None
+        self._t0 = self._tag = None
+        self.proxy_workgroups = 0              # one-rank diagnostics: footprint of a ring kernel behind every all-reduce
         with device_of(device):             # ncclCommInitRank binds the CALLING THREAD's current device; restored after
             self._init(rank, world, device, group, store)
 
@@ -70,13 +76,17 @@ class NativeCommunicator:
         if world > 1:
             import torch.distributed as td
             if store is not None:
+                # every rank opens its communicators in the same order: the sequence number keys the id of THIS one
+                key = f"ddl_rccl_id/{NativeCommunicator._store_seq}"
+                NativeCommunicator._store_seq += 1
                 if rank == 0:
-                    store.set("ddl_rccl_id", bytes(ident))
+                    store.set(key, bytes(ident))
                 else:
-                    C.memmove(ident, store.get("ddl_rccl_id"), 128)
+                    C.memmove(ident, store.get(key), 128)
             elif td.is_available() and td.is_initialized():
+                from ..dist import control_device
                 t = torch.frombuffer(bytearray(bytes(ident)), dtype=torch.uint8).clone()
-                dev_t = t.to(device) if td.get_backend(group) == "nccl" else t
+                dev_t = t.to(control_device(group, device))
                 td.broadcast(dev_t, 0, group=group)
                 C.memmove(ident, bytes(dev_t.cpu().numpy().tobytes()), 128)
             else:
@@ -102,15 +112,37 @@ class NativeCommunicator:
         return int(self.lib.ddl_comm_user_rank(self._comm))
 
     # ------------------------------------------------------------------ plumbing
-    def _enter(self) -> int:
+    def _enter(self, tag=None) -> int:
         """Order the comm stream behind everything enqueued on the current stream; returns its raw handle."""
         self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        if self.profile is not None:
+            self._t0 = torch.cuda.Event(enable_timing=True)
+            self._t0.record(self.stream)
+            self._tag = tag
         return self.stream.cuda_stream
 
     def _done(self) -> _Handle:
+        if self.profile is not None:                          # diagnostics: time every collective on the comm stream
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(self.stream)
+            self.profile.append((self._t0, ev, self._tag))
+            return _Handle(ev, self.device)
         ev = torch.cuda.Event()
         ev.record(self.stream)
         return _Handle(ev, self.device)
+
+    def start_profile(self) -> None:
+        """From now on every collective is bracketed by timing events on the communicator's stream."""
+        self.profile = []
+
+    def stop_profile(self):
+        """-> [(tag, milliseconds)] of the collectives since :meth:`start_profile` (host-blocking)."""
+        rec, self.profile = self.profile or [], None
+        out = []
+        for t0, t1, tag in rec:
+            t1.synchronize()
+            out.append((tag, t0.elapsed_time(t1)))
+        return out
 
     @staticmethod
     def _dt(t: torch.Tensor) -> int:
@@ -119,18 +151,21 @@ class NativeCommunicator:
         return _DT[t.dtype]
 
     # ------------------------------------------------------------------ collectives (asynchronous)
-    def all_reduce(self, t: torch.Tensor, average: bool = True) -> _Handle:
+    def all_reduce(self, t: torch.Tensor, average: bool = True, tag=None) -> _Handle:
         with device_of(self.device):
-            st = self._enter()
+            st = self._enter(tag if tag is not None else ("all_reduce", t.numel() * t.element_size()))
             check(self.lib.ddl_comm_all_reduce(self._comm, t.data_ptr(), t.data_ptr(), t.numel(), self._dt(t),
                                                int(average), st), "ncclAllReduce")
+            if self.proxy_workgroups > 0 and self.world == 1:
+                check(self.lib.ddl_stream_proxy(t.data_ptr(), t.numel() * t.element_size(), int(self.proxy_workgroups), 2,
+                                                st), "ddl_stream_proxy")
             return self._done()
 
-    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, average: bool = True) -> _Handle:
+    def reduce_scatter(self, out: torch.Tensor, inp: torch.Tensor, average: bool = True, tag=None) -> _Handle:
         if inp.numel() != out.numel() * self.world or inp.dtype != out.dtype:
             raise ValueError("reduce_scatter: input must hold world x output elements of the same dtype")
         with device_of(self.device):
-            st = self._enter()
+            st = self._enter(tag if tag is not None else ("reduce_scatter", inp.numel() * inp.element_size()))
             check(self.lib.ddl_comm_reduce_scatter(self._comm, inp.data_ptr(), out.data_ptr(), out.numel(),
                                                    self._dt(out), int(average), st), "ncclReduceScatter")
             return self._done()
@@ -139,14 +174,14 @@ class NativeCommunicator:
         if out.numel() != inp.numel() * self.world or inp.dtype != out.dtype:
             raise ValueError("all_gather: output must hold world x input elements of the same dtype")
         with device_of(self.device):
-            st = self._enter()
+            st = self._enter(("all_gather", out.numel() * out.element_size()))
             check(self.lib.ddl_comm_all_gather(self._comm, inp.data_ptr(), out.data_ptr(), inp.numel(), self._dt(inp),
                                                st), "ncclAllGather")
             return self._done()
 
     def broadcast(self, t: torch.Tensor, root: int = 0) -> _Handle:
         with device_of(self.device):
-            st = self._enter()
+            st = self._enter(("broadcast", t.numel() * t.element_size()))
             check(self.lib.ddl_comm_broadcast(self._comm, t.data_ptr(), t.numel(), self._dt(t), root, st), "ncclBroadcast")
             return self._done()
 

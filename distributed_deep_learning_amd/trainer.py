@@ -11,6 +11,7 @@ Differences are the fixes listed in SURVEY Appendix A: gradients really are sync
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import List, Optional
 
@@ -104,9 +105,12 @@ class Trainer:
         cfg, info = self.cfg, self.info
         self.devices = self._devices()
         self.in_device, self.out_device = self.devices[0], self.devices[-1]
-        external = info.launcher in ("torchrun", "mpi", "slurm") and "MASTER_PORT" in __import__("os").environ
+        external = info.launcher in ("torchrun", "mpi", "slurm") and "MASTER_PORT" in os.environ
+        # control plane: gloo beside the native RCCL data plane (one communicator per stage device, none of them bound
+        # to the process group); ``--comm torch``: an nccl group, left UNBOUND when this rank drives several GPUs
         ddist.init(info, self.in_device, master_addr=None if external else cfg.master_addr,
-                   master_port=None if external else cfg.master_port)
+                   master_port=None if external else cfg.master_port, comm=cfg.comm,
+                   bind_device=cfg.mode not in ("model", "pipeline"))
         torch.manual_seed(cfg.seed)                           # reference: torch.manual_seed(42), main.py:132
 
         model = models.build(cfg.model, **_model_kwargs(cfg))
@@ -203,8 +207,9 @@ class Trainer:
         """The captured-graph path (``--graph``): single process, one device, fixed batch shape."""
         cfg = self.cfg
         want = cfg.graph if cfg.graph is not None else cfg.model in _GRAPH_AUTO_MODELS
-        # several ranks: only on request, and only when the collectives can be captured (native communicator)
-        multi_ok = cfg.graph is True and cfg.comm == "native"
+        # several ranks: whenever the collectives can be captured, i.e. the native communicator moves the gradients
+        live = [d for d in getattr(self, "ddps", []) if d is not None]
+        multi_ok = cfg.comm == "native" and len(live) == 1 and live[0].ncomm is not None
         ok = (want and (self.info.world == 1 or multi_ok) and cfg.mode in ("sequential", "data") and x.is_cuda
               and len(self.optimizers) == 1 and hasattr(self.criterion, "last_correct"))
         if not ok:

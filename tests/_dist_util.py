@@ -1,4 +1,10 @@
-"""Spawn helper for multi-process gloo tests (world_size > 1 on CPU, rendezvous on 127.0.0.1)."""
+"""Spawn helper for multi-process tests, rendezvous on 127.0.0.1.
+
+``backend="gloo"``: CPU tensors, any world size (the tier that runs everywhere).
+``backend="rccl"``: rank r owns ``cuda:r``; the process group is the framework's own bootstrap
+(``distributed_deep_learning_amd.dist.init``: gloo control plane + native RCCL data plane, or an nccl group for
+``comm="torch"``).  Tests of this tier carry ``@pytest.mark.gpu`` and ``skipif(visible_gpus() < world)``: they skip with
+a reason on a 1-GPU box and run unchanged on an 8-GPU node.  Workers find their device through :func:`device`."""
 import os
 import socket
 import traceback
@@ -35,12 +41,35 @@ def _unplain(o):
     return o
 
 
-def _entry(rank, world, port, fn, args, q):
+def device() -> torch.device:
+    """The device of the calling test rank (``cpu`` under gloo, ``cuda:LOCAL_RANK`` under rccl)."""
+    return torch.device(os.environ.get("DDL_TEST_DEVICE", "cpu"))
+
+
+def visible_gpus() -> int:
+    """GPUs on this machine, counted without initialising HIP in the pytest process."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    from distributed_deep_learning_amd.utils.host import visible_gpus as count
+    return max(0, count())
+
+
+def _entry(rank, world, port, fn, args, q, backend="gloo", comm="native"):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                          LOCAL_RANK=str(rank))
+                          LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
         torch.set_num_threads(2)
-        td.init_process_group("gloo", rank=rank, world_size=world)
+        if backend == "rccl":
+            from distributed_deep_learning_amd import dist as ddist
+            dev = torch.device(f"cuda:{rank}")
+            os.environ["DDL_TEST_DEVICE"] = str(dev)
+            os.environ["DDL_TEST_COMM"] = comm
+            ddist.init(ddist.RankInfo(rank, world, rank, world, "spawn"), dev, comm=comm, force=True, timeout_s=240.0)
+        else:
+            os.environ["DDL_TEST_DEVICE"] = "cpu"
+            td.init_process_group("gloo", rank=rank, world_size=world)
         out = fn(rank, world, *args)
         q.put((rank, "ok", _plain(out)))
         td.barrier()
@@ -50,12 +79,12 @@ def _entry(rank, world, port, fn, args, q):
         raise
 
 
-def run_ranks(fn, world=2, args=()):
-    """Run ``fn(rank, world, *args)`` on ``world`` gloo ranks; returns the list of per-rank results."""
+def run_ranks(fn, world=2, args=(), backend="gloo", comm="native"):
+    """Run ``fn(rank, world, *args)`` on ``world`` ranks (gloo / CPU or rccl / one GPU each); returns the per-rank results."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, q)) for r in range(world)]
+    procs = [ctx.Process(target=_entry, args=(r, world, port, fn, args, q, backend, comm)) for r in range(world)]
     for p in procs:
         p.start()
     results = {}

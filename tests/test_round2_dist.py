@@ -99,8 +99,9 @@ def test_bench_self_launch_starts_one_child_per_gpu(monkeypatch, tmp_path):
             pass
 
     FakeProc.fail = False
-    monkeypatch.setattr(torch.cuda, "device_count", lambda: 4)
-    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None: FakeProc(cmd, env))
+    from distributed_deep_learning_amd.utils import host
+    monkeypatch.setattr(host, "visible_gpus", lambda: 4)      # the launcher counts GPUs without touching HIP
+    monkeypatch.setattr(bench.subprocess, "Popen", lambda cmd, env=None, stdout=None: FakeProc(cmd, env))
     a = bench.build_parser().parse_args(["--gpus", "4"])
     assert bench.self_launch(a, ["--gpus", "4"]) == 0
     assert [c[1]["RANK"] for c in calls] == ["0", "1", "2", "3"]
