@@ -68,8 +68,10 @@ __global__ __launch_bounds__(256) void linear_epilogue_kernel(const float* __res
 }
 
 // ---------------------------------------------------------------- backward gate
-// g = dy * [y > 0] * scale (GATE) or dy * scale; db[c] (+)= sum_r g[r][c].  One pass over the gradient.
-template <bool GATE>
+// g = dy * gate(y) * scale or dy * scale; db[c] (+)= sum_r g[r][c].  One pass over the gradient.
+// GATE 1: gate = [y > 0] - ReLU, with or without dropout behind it (a dropped element is 0).  GATE 2: gate = [y != 0] -
+// dropout WITHOUT ReLU, where a kept element may be negative (a kept element that is exactly 0 has measure zero).
+template <int GATE>
 __global__ __launch_bounds__(256) void linear_bwd_gate_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ y,
                                                               bf16_t* __restrict__ g, float* __restrict__ db, int M, int C,
                                                               int c8, float scale) {
@@ -86,11 +88,11 @@ __global__ __launch_bounds__(256) void linear_bwd_gate_kernel(const bf16_t* __re
       const size_t off = (size_t)row * C + (size_t)chunk * 8;
       float f[8];
       unpack8(*reinterpret_cast<const u32x4*>(dy + off), f);
-      if (GATE) {
+      if (GATE != 0) {
         float yf[8];
         unpack8(*reinterpret_cast<const u32x4*>(y + off), yf);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = yf[e] > 0.f ? f[e] * scale : 0.f;
+        for (int e = 0; e < 8; ++e) f[e] = (GATE == 1 ? yf[e] > 0.f : yf[e] != 0.f) ? f[e] * scale : 0.f;
       } else if (scale != 1.f) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] *= scale;
@@ -194,7 +196,7 @@ extern "C" int ddl_linear_epilogue(const float* acc, const float* bias, void* y,
 
 // g may be null (only the bias gradient is wanted), y null = no gate, db null = no bias.  accumulate: add into db.
 extern "C" int ddl_linear_bwd_gate(const void* dy, const void* y, void* g, float* db, int M, int C, float scale,
-                                   int accumulate, void* stream) {
+                                   int accumulate, int gate_nonzero, void* stream) {
   if (C % 8 != 0 || M <= 0) return -1;
   hipStream_t st = (hipStream_t)stream;
   if (db != nullptr && !accumulate) {
@@ -206,11 +208,14 @@ extern "C" int ddl_linear_bwd_gate(const void* dy, const void* y, void* g, float
   long long gx = ((long long)M + rp * 4 - 1) / (rp * 4);
   if (gx < 1) gx = 1;
   if (gx > 1024) gx = 1024;
-  if (y != nullptr)
-    hipLaunchKernelGGL((linear_bwd_gate_kernel<true>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
+  if (y != nullptr && gate_nonzero)
+    hipLaunchKernelGGL((linear_bwd_gate_kernel<2>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)y, (bf16_t*)g, db, M, C, c8, scale);
+  else if (y != nullptr)
+    hipLaunchKernelGGL((linear_bwd_gate_kernel<1>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
                        (const bf16_t*)y, (bf16_t*)g, db, M, C, c8, scale);
   else
-    hipLaunchKernelGGL((linear_bwd_gate_kernel<false>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
+    hipLaunchKernelGGL((linear_bwd_gate_kernel<0>), dim3((unsigned)gx, gy), dim3(256), 0, st, (const bf16_t*)dy,
                        (const bf16_t*)nullptr, (bf16_t*)g, db, M, C, c8, scale);
   return (int)hipGetLastError();
 }

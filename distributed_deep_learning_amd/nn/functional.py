@@ -749,8 +749,9 @@ class LinearAct(torch.autograd.Function):
     gradient accumulated straight into the arena on the side stream.
 
     ``w16`` bf16 ``[out_p, in_p]`` and ``w16_t`` bf16 ``[in_p, out_p]`` are the (8-padded) weight and its transpose —
-    the arena's shadow pair when the parameter lives there.  No dropout mask is stored: a kept, live element is one
-    with ``y > 0``.  Reference: every model of the reference ends in ``nn.Linear``
+    the arena's shadow pair when the parameter lives there.  No dropout mask is stored: behind a ReLU a kept, live
+    element is one with ``y > 0``; dropout WITHOUT ReLU keeps negative values too, there the gate is ``y != 0``.
+    Reference: every model of the reference ends in ``nn.Linear``
     (``/root/reference/src/pytorch/CNN/model.py:183``, ``MLP/model.py:51-58``, ``LSTM/model.py:94``)."""
 
     @staticmethod
@@ -775,6 +776,7 @@ class LinearAct(torch.autograd.Function):
         gated = relu or drop_p > 0.0
         ctx.save_for_backward(xs, y if gated else None, w16)
         ctx.meta = (B, fin, out_f, gated, 1.0 / (1.0 - drop_p) if drop_p > 0.0 else 1.0)
+        ctx.gate_nonzero = bool(drop_p > 0.0 and not relu)
         ctx.weight, ctx.bias = weight, bias
         return y if (Bp == B and out_p == out_f) else y[:B, :out_f]
 
@@ -796,7 +798,8 @@ class LinearAct(torch.autograd.Function):
         direct_b = (arena_b is not None and out_p == out_f and arena_b.grad_is_arena_view(bias) and bias.grad.is_contiguous())
         if gated or has_bias or scale != 1.0:
             g, dbv = K.linear_bwd_gate(dy, y if gated else None, scale, grad_out=bias.grad if direct_b else None,
-                                       want_bias=has_bias, want_g=gated or scale != 1.0)
+                                       want_bias=has_bias, want_g=gated or scale != 1.0,
+                                       gate_nonzero=ctx.gate_nonzero)
             if g is None:
                 g = dy
             if has_bias:

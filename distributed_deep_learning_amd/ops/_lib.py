@@ -69,7 +69,7 @@ _SIGS = {
     "ddl_flat_sgd": [_vp] * 9 + [_i, _i, _i, _vp],
     "ddl_flat_adam": [_vp] * 8 + [_i, _i, _i, _vp],
     "ddl_linear_epilogue": [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
-    "ddl_linear_bwd_gate": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "ddl_linear_bwd_gate": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
     "ddl_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _ll, _vp],
     "ddl_cast_rows": [_vp, _vp, _i, _i, _ll, _vp],
     "ddl_l1_loss": [_vp, _i, _vp, _vp, _vp, _ll, _vp],

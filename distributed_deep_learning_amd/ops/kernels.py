@@ -817,8 +817,10 @@ def linear_epilogue(acc: torch.Tensor, bias, rows: int, relu: bool = False, drop
     return y
 
 
-def linear_bwd_gate(dy: torch.Tensor, y, scale: float = 1.0, grad_out=None, want_bias: bool = True, want_g: bool = True):
-    """``g = dy * [y > 0] * scale`` (``y`` given: ReLU and / or dropout gate) or ``dy * scale``; the bias gradient
+def linear_bwd_gate(dy: torch.Tensor, y, scale: float = 1.0, grad_out=None, want_bias: bool = True, want_g: bool = True,
+                    gate_nonzero: bool = False):
+    """``g = dy * [y > 0] * scale`` (``y`` given: ReLU, with or without dropout behind it), ``dy * [y != 0] * scale``
+    (``gate_nonzero``: dropout WITHOUT ReLU - kept elements may be negative) or ``dy * scale``; the bias gradient
     ``sum_rows g`` goes to a fresh fp32 ``[C]`` tensor or is ACCUMULATED into ``grad_out``.  Returns ``(g, db)``."""
     lib = _lib.require()
     _chk_act(dy, "linear_bwd_gate")
@@ -835,7 +837,7 @@ def linear_bwd_gate(dy: torch.Tensor, y, scale: float = 1.0, grad_out=None, want
         else:
             db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
     check(lib.ddl_linear_bwd_gate(ptr(dy), ptr(y), ptr(g), ptr(db), M, Cc, float(scale), int(grad_out is not None),
-                                  stream_ptr()), "linear_bwd_gate")
+                                  int(bool(gate_nonzero)), stream_ptr()), "linear_bwd_gate")
     return g, db
 
 

@@ -308,6 +308,35 @@ def test_linear_gradients_go_straight_into_the_arena_and_dropout_gates_backward(
     _close(lin(x, relu=True, dropout=0.5), ref, what="eval mode: no dropout")
 
 
+def test_linear_dropout_without_relu_keeps_the_gradient_of_negative_outputs():
+    """Dropout behind a Linear with NO ReLU: kept elements may be negative, so the backward gate is ``y != 0`` (the
+    dropped elements), not ``y > 0``.  The mask is read back from the forward output and the gradients are compared
+    with fp32 autograd through that fixed mask."""
+    from distributed_deep_learning_amd import nn as dnn
+    torch.manual_seed(11)
+    lin = dnn.Linear(384, 200).to(_dev())
+    x = torch.randn((48, 384), device=_dev()).to(torch.bfloat16).requires_grad_(True)
+    lin.train()
+    y = lin(x, relu=False, dropout=0.25)
+    yd = y.detach().float()
+    mask = (yd != 0).float()
+    assert 0.70 < mask.mean().item() < 0.80, mask.mean().item()
+    assert (yd < 0).float().mean().item() > 0.25                                # negative outputs survive
+    wq = lin.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    bq = lin.bias.detach().clone().requires_grad_(True)
+    xr = x.detach().float().requires_grad_(True)
+    ref = F.linear(xr, wq, bq) * mask / 0.75
+    _close(y, ref, what="linear + dropout fwd")
+    dy = torch.randn(y.shape, device=_dev()).to(torch.bfloat16)
+    y.backward(dy)
+    from distributed_deep_learning_amd.ops import streams
+    streams.join()
+    ref.backward(dy.float())
+    _close(x.grad, xr.grad, what="dx through the dropout-only gate")
+    _close(lin.weight.grad, wq.grad, rtol=1e-2, atol=1e-2 * wq.grad.abs().max().item(), what="dW through the dropout-only gate")
+    _close(lin.bias.grad, bq.grad, rtol=1e-2, atol=1e-2 * max(1.0, bq.grad.abs().max().item()), what="db through the dropout-only gate")
+
+
 def test_l1_loss_kernel_matches_torch():
     from distributed_deep_learning_amd import nn as dnn
     g = torch.Generator().manual_seed(9)
