@@ -9,9 +9,19 @@
 // elements of one channel per lane.  A and B use the identical read pattern, so the reduction order matches.
 //
 // Grid: (K tiles) x (S*C tiles) x R x split-M.  Each block walks its slice of M in 64-pixel steps
-// (double-buffered LDS, register staging with zero fill for padding) and accumulates its fp32 tile into dw
-// with global float atomics (dw must be zeroed by the caller); split-M is sized so the grid fills 256 CUs
-// while the atomic traffic stays a small multiple of the weight size.
+// (double-buffered LDS, register staging with zero fill for padding); split-M is sized so the grid fills 256 CUs.
+// The split-M partial tiles meet in one of two ways:
+//   * workspace given (the default, ops/kernels.py): every block STORES its fp32 tile into its split's slab of the
+//     workspace ([splits][K][R][S*C], plain coalesced stores) and wgrad_reduce_kernel adds the slabs to dw in a FIXED
+//     order - the gradient is bit-reproducible from run to run;
+//   * no workspace (or one split only): global float atomics into dw, as in rounds 1-2 (order of the adds, and with
+//     it the last bits of the result, differ from run to run).
+// Either way dw is ACCUMULATED into (zero it for a plain product).
+//
+// Cost of the reproducible mode, measured (profiles/r3_wgrad_reproducible.txt): +0.4-0.5 ms per ResNet-50 step (0.6 % at
+// batch 1000, 1.3 % at 512).  It is BYTES, not launches: the slabs are written and read once more than the atomics'
+// traffic (~1.5 GB per step) in a step that is HBM-bound; running the reduce on a third stream, or inside the first
+// microseconds of the NEXT filter gradient's kernel (no extra launch at all), measured the same or worse.
 #include "common.h"
 #include "host_util.h"
 #include <stdlib.h>
@@ -20,6 +30,11 @@ struct WgradParams {
   const bf16_t* dy;   // [M][K]
   const bf16_t* x;    // [N][H][W][C]
   float* dw;          // [K][R][S*C]
+  float* part;        // null, or the workspace [splits][K][R][S*C]: blocks store their tiles instead of adding atomically
+  long long part_stride;   // K*R*S*C
+  int plan_only;      // host: stop after sizing the grid (ddl_conv_wgrad_plan)
+  float* ws;          // host: caller's workspace (may be null) and its size in floats
+  long long ws_elems;
   int N, H, W, C, K, P, Q, R, S, stride, pad;
   int M, SC;
   int tiles_k, tiles_n, splits, m_per_split;
@@ -191,7 +206,7 @@ __global__ __launch_bounds__(256 * G) void conv_wgrad_kernel(const WgradParams p
 
   // ---- epilogue: D[row = k channel][col = (s,c)] -> fp32 tile in LDS -> row-contiguous float atomics ----
   // (each wave-instruction adds 256 contiguous bytes of one dw row: the shape the memory-side atomic units like)
-  if (nsteps > 0) {
+  if (nsteps > 0 || p.part != nullptr) {                       // (a slab is written even by a block without pixels)
     float* const Ts = reinterpret_cast<float*>(smem);          // [TK][TN] fp32, reuses the staging buffers
 #pragma unroll
     for (int gsel = 0; gsel < G; ++gsel) {                      // group 0 stores its tile, group 1 adds its own
@@ -212,11 +227,15 @@ __global__ __launch_bounds__(256 * G) void conv_wgrad_kernel(const WgradParams p
       __syncthreads();
     }
     constexpr int LPR = TN / 64;                                // 64-lane pieces per row
+    float* const out = p.part != nullptr ? p.part + (size_t)split * (size_t)p.part_stride : p.dw;
     for (int it = wid + 4 * grp; it < TK * LPR; it += 4 * G) {
       const int row = it / LPR, col = (it - row * LPR) * 64 + lane;
       const int k = k0 + row, cn = nn0 + col;
-      if (k < p.K && cn < p.SC)
-        atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[row * TN + col]);
+      if (k < p.K && cn < p.SC) {
+        float* const dst = out + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn;
+        if (p.part != nullptr) *dst = Ts[row * TN + col];
+        else atomicAdd(dst, Ts[row * TN + col]);
+      }
     }
   }
 }
@@ -483,8 +502,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_ring_kernel(const WgradPar
   wg_wait_vmcnt<0>();                            // the trailing zero fills must land before the ring is reused
   __syncthreads();
 
-  if (nsteps > 0) {
+  if (nsteps > 0 || p.part != nullptr) {
     constexpr int TNW = TN * NSUB;
+    float* const out = p.part != nullptr ? p.part + (size_t)split * (size_t)p.part_stride : p.dw;
     // fp32 tile through the ring, in EH passes of TK/EH rows when the whole tile does not fit
     constexpr int EH = (TK * TNW * 4 + NS * STAGE - 1) / (NS * STAGE);
     constexpr int WKH = WK / EH, FKH = FK / EH;
@@ -510,15 +530,86 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_ring_kernel(const WgradPar
         const int lr = it / LPR, col = (it - lr * LPR) * 64 + lane;
         const int row = (lr / WKH) * WK + h * WKH + (lr % WKH);
         const int k = k0 + row, cn = nn0 + col;
+        float* dst = nullptr;
         if (FOLD) {                                // cn runs over (r, s, c): the filter row is part of the column
-          if (k < p.K && cn < p.R * p.SC)
-            atomicAdd(p.dw + (size_t)k * (size_t)p.R * (size_t)p.SC + (size_t)cn, Ts[lr * TNW + col]);
+          if (k < p.K && cn < p.R * p.SC) dst = out + (size_t)k * (size_t)p.R * (size_t)p.SC + (size_t)cn;
         } else if (k < p.K && cn < p.SC) {
-          atomicAdd(p.dw + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn, Ts[lr * TNW + col]);
+          dst = out + ((size_t)k * (size_t)p.R + (size_t)r) * (size_t)p.SC + (size_t)cn;
+        }
+        if (dst != nullptr) {
+          if (p.part != nullptr) *dst = Ts[lr * TNW + col];
+          else atomicAdd(dst, Ts[lr * TNW + col]);
         }
       }
     }
   }
+}
+
+// dw[e] += sum_s part[s][e] with the splits summed in a FIXED order: split-lane ty of a block adds splits ty, ty + NY, ...
+// front to back, and the NY partial sums are combined in a fixed order through LDS.  NX lanes of 16 bytes side by side:
+// NX = 64 (1 KiB per wave-load) for big filters; NX = 16 with 64 split-lanes for small filters with hundreds of splits
+// (a 64 x 64 1x1 filter has 1024 column groups: 16 blocks of the wide shape would leave the chip empty).
+template <int NX, int NY>
+__global__ __launch_bounds__(NX * NY) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                               long long n4, long long stride, int splits) {
+  __shared__ f32x4 red[NY][NX];
+  const int tx = threadIdx.x % NX, ty = threadIdx.x / NX;
+  const long long e = (long long)blockIdx.x * NX + tx;
+  f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (e < n4) {
+    const float* src = part + e * 4 + (long long)ty * stride;
+#pragma unroll 4
+    for (int sp = ty; sp < splits; sp += NY, src += (long long)NY * stride) s += *reinterpret_cast<const f32x4*>(src);
+  }
+  red[ty][tx] = s;
+  __syncthreads();
+  if constexpr (NY > 16) {                         // two ordered levels: 8 groups of NY/8, then the 8 group sums
+    if (ty < 8) {
+      f32x4 t = red[ty * (NY / 8)][tx];
+#pragma unroll
+      for (int y = 1; y < NY / 8; ++y) t += red[ty * (NY / 8) + y][tx];
+      red[ty * (NY / 8)][tx] = t;
+    }
+    __syncthreads();
+    if (ty == 0 && e < n4) {
+      f32x4 t = red[0][tx];
+#pragma unroll
+      for (int y = 1; y < 8; ++y) t += red[y * (NY / 8)][tx];
+      f32x4* const d = reinterpret_cast<f32x4*>(dw + e * 4);
+      *d = *d + t;
+    }
+  } else if (ty == 0 && e < n4) {
+    f32x4 t = red[0][tx];
+#pragma unroll
+    for (int y = 1; y < NY; ++y) t += red[y][tx];
+    f32x4* const d = reinterpret_cast<f32x4*>(dw + e * 4);
+    *d = *d + t;
+  }
+}
+
+// Called by every launcher once the split count is known: picks the meeting mode (see the file header).  Returns false
+// when only the plan was wanted.
+static bool wgrad_prepare(WgradParams& p) {
+  p.part_stride = (long long)p.K * p.R * p.SC;
+  p.part = nullptr;
+  if (p.plan_only) return false;
+  if (p.ws != nullptr && p.splits > 1 && (long long)p.splits * p.part_stride <= p.ws_elems && p.part_stride % 4 == 0)
+    p.part = p.ws;
+  return true;
+}
+static int wgrad_finish(const WgradParams& p, hipStream_t stream) {
+  const int rc = (int)hipGetLastError();
+  if (rc != 0 || p.part == nullptr) return rc;
+  const long long n4 = p.part_stride / 4;
+  const unsigned grid = (unsigned)((n4 + 63) / 64);
+  if (p.splits <= 8)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<64, 4>), dim3(grid), dim3(256), 0, stream, p.part, p.dw, n4, p.part_stride, p.splits);
+  else if (grid >= 512 || p.splits < 64)
+    hipLaunchKernelGGL((wgrad_reduce_kernel<64, 16>), dim3(grid), dim3(1024), 0, stream, p.part, p.dw, n4, p.part_stride, p.splits);
+  else
+    hipLaunchKernelGGL((wgrad_reduce_kernel<16, 64>), dim3((unsigned)((n4 + 15) / 16)), dim3(1024), 0, stream, p.part, p.dw,
+                       n4, p.part_stride, p.splits);
+  return (int)hipGetLastError();
 }
 
 template <int TK, int TN, int G>
@@ -527,7 +618,7 @@ static int launch_wgrad_g(WgradParams& p, hipStream_t stream, int smem, unsigned
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_kernel<TK, TN, G>), smem);
   if (rc != 0) return rc;
   hipLaunchKernelGGL((conv_wgrad_kernel<TK, TN, G>), dim3(grid), dim3(256 * G), smem, stream, p);
-  return (int)hipGetLastError();
+  return wgrad_finish(p, stream);
 }
 
 template <int TK, int TN>
@@ -565,13 +656,14 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   splits = (p.M + mps - 1) / mps;
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
+  if (!wgrad_prepare(p)) return 0;
   const unsigned grid = (unsigned)(tiles * splits);
   if (ring) {
     static SmemAttrOnce once_ring;
     const int rc = once_ring.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN>), smem);
     if (rc != 0) return rc;
     hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN>), dim3(grid), dim3(256), smem, stream, p);
-    return (int)hipGetLastError();
+    return wgrad_finish(p, stream);
   }
   if (G == 2) return launch_wgrad_g<TK, TN, 2>(p, stream, smem, grid);
   return launch_wgrad_g<TK, TN, 1>(p, stream, smem, grid);
@@ -592,11 +684,12 @@ static int launch_wgrad_fold(WgradParams& p, hipStream_t stream) {
   splits = (p.M + mps - 1) / mps;
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
+  if (!wgrad_prepare(p)) return 0;
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB, FOLD>), smem);
   if (rc != 0) return rc;
   hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB, FOLD>), dim3((unsigned)splits), dim3(256), smem, stream, p);
-  return (int)hipGetLastError();
+  return wgrad_finish(p, stream);
 }
 
 // Wide launch: [128][256] tiles of one filter row, three ring stages (72 KiB: two blocks per CU, as the 128 x 128 tile).
@@ -615,32 +708,18 @@ static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
   splits = (p.M + mps - 1) / mps;
   p.splits = (int)splits;
   p.m_per_split = (int)mps;
+  if (!wgrad_prepare(p)) return 0;
   // (eight waves per block, 64 x 64 each, measured 0.1 % slower in the step than four waves of 64 x 128)
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_ring_kernel<TK, TN, NSUB, false, NS>), smem);
   if (rc != 0) return rc;
   hipLaunchKernelGGL((conv_wgrad_ring_kernel<TK, TN, NSUB, false, NS>), dim3((unsigned)(tiles * splits)), dim3(256), smem, stream, p);
-  return (int)hipGetLastError();
+  return wgrad_finish(p, stream);
 }
 
-// dw (fp32, [K][R][S][C]) must be zero on entry: the kernel accumulates with atomics.
-extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int P,
-                              int Q, int R, int S, int stride, int pad, void* stream) {
-  if (C % 8 != 0 || K % 8 != 0) return -1;
-  const long long M = (long long)N * P * Q;
-  if (M >= (1ll << 31) || (long long)N * H * W >= (1ll << 31) || M <= 0) return -3;
-  WgradParams p;
-  p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw;
-  p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
-  p.M = (int)M; p.SC = S * C;
-  p.plain = (R == 1 && S == 1 && stride == 1 && pad == 0 && P == H && Q == W) ? 1 : 0;
-  p.div_pq = make_fastdiv((unsigned)(P * Q));
-  p.div_q = make_fastdiv((unsigned)Q);
-  p.div_c = make_fastdiv((unsigned)C);
-  p.div_sc = make_fastdiv((unsigned)(S * C));
-  p.dy_bytes = (unsigned long long)M * K * 2ull;
-  p.x_bytes = (unsigned long long)N * H * W * C * 2ull;
-  hipStream_t st = (hipStream_t)stream;
+// The work of ddl_conv_wgrad / ddl_conv_wgrad_plan: fills the problem, picks the tile family, sizes the grid, launches.
+static int wgrad_dispatch(WgradParams& p, hipStream_t st) {
+  const int K = p.K, R = p.R;
   // small filters on few channels (the space-to-depth stem: 4 x 4 x 16): all filter rows in one block, dy staged once
   static const int fold_on = [] { const char* e = getenv("DDL_WGRAD_FOLD"); return e ? atoi(e) : 1; }();
   if (fold_on && K <= 64 && R > 1 && R * p.SC <= 256 && R * p.SC > 128 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)
@@ -661,4 +740,45 @@ extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, i
   if (k64) return launch_wgrad<64, 128>(p, st);
   if (n64) return launch_wgrad<128, 64>(p, st);
   return launch_wgrad<128, 128>(p, st);
+}
+
+static int wgrad_fill(WgradParams& p, const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int P,
+                      int Q, int R, int S, int stride, int pad) {
+  if (C % 8 != 0 || K % 8 != 0) return -1;
+  const long long M = (long long)N * P * Q;
+  if (M >= (1ll << 31) || (long long)N * H * W >= (1ll << 31) || M <= 0) return -3;
+  p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.dw = dw;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.K = K; p.P = P; p.Q = Q; p.R = R; p.S = S; p.stride = stride; p.pad = pad;
+  p.M = (int)M; p.SC = S * C;
+  p.plain = (R == 1 && S == 1 && stride == 1 && pad == 0 && P == H && Q == W) ? 1 : 0;
+  p.div_pq = make_fastdiv((unsigned)(P * Q));
+  p.div_q = make_fastdiv((unsigned)Q);
+  p.div_c = make_fastdiv((unsigned)C);
+  p.div_sc = make_fastdiv((unsigned)(S * C));
+  p.dy_bytes = (unsigned long long)M * K * 2ull;
+  p.x_bytes = (unsigned long long)N * H * W * C * 2ull;
+  p.part = nullptr; p.part_stride = 0; p.plan_only = 0; p.ws = nullptr; p.ws_elems = 0; p.splits = 1;
+  return 0;
+}
+
+// dw (fp32, [K][R][S][C]) is ACCUMULATED into.  ws: null (float atomics) or a scratch buffer of ws_elems floats, at least
+// ddl_conv_wgrad_plan(...) of them (split-M partial slabs + ordered reduce: reproducible to the bit).
+extern "C" int ddl_conv_wgrad(const void* dy, const void* x, float* dw, int N, int H, int W, int C, int K, int P,
+                              int Q, int R, int S, int stride, int pad, float* ws, long long ws_elems, void* stream) {
+  WgradParams p;
+  const int rc = wgrad_fill(p, dy, x, dw, N, H, W, C, K, P, Q, R, S, stride, pad);
+  if (rc != 0) return rc;
+  p.ws = ws; p.ws_elems = ws_elems;
+  return wgrad_dispatch(p, (hipStream_t)stream);
+}
+
+// Floats of workspace the reproducible mode needs for this problem (0: one split, nothing to reduce); < 0: bad problem.
+extern "C" long long ddl_conv_wgrad_plan(int N, int H, int W, int C, int K, int P, int Q, int R, int S, int stride, int pad) {
+  WgradParams p;
+  const int rc = wgrad_fill(p, nullptr, nullptr, nullptr, N, H, W, C, K, P, Q, R, S, stride, pad);
+  if (rc != 0) return rc;
+  p.plan_only = 1;
+  const int rc2 = wgrad_dispatch(p, nullptr);
+  if (rc2 != 0) return rc2 < 0 ? rc2 : -rc2;
+  return p.splits > 1 ? (long long)p.splits * p.part_stride : 0;
 }

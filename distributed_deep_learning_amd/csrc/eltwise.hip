@@ -377,6 +377,55 @@ extern "C" int ddl_stream_proxy(void* buf, long long bytes, int workgroups, int 
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------- PS / ZeRO-1 pull: masters of the foreign ranges
+// After the bf16 shadow of every shard has been gathered, the fp32 masters of the ranges OTHER ranks own are refreshed:
+// (1) one launch casts every foreign range from the shadow (ranges = [lo, hi) pairs, multiples of 8, blockIdx.y = range);
+// (2) the parameters that kernels consume in fp32 travel exactly: pack (owned values, zero elsewhere) -> one small
+//     all-reduce -> scatter.  idx = arena positions, own = 1 where this rank owns the position.
+__global__ __launch_bounds__(256) void cast_ranges_kernel(const bf16_t* __restrict__ shadow, float* __restrict__ master,
+                                                          const long long* __restrict__ ranges) {
+  const long long lo = ranges[2 * blockIdx.y], hi = ranges[2 * blockIdx.y + 1];
+  const long long n8 = (hi - lo) / 8;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    float f[8];
+    unpack8(*reinterpret_cast<const u32x4*>(shadow + lo + i * 8), f);
+    *reinterpret_cast<f32x4*>(master + lo + i * 8) = f32x4{f[0], f[1], f[2], f[3]};
+    *reinterpret_cast<f32x4*>(master + lo + i * 8 + 4) = f32x4{f[4], f[5], f[6], f[7]};
+  }
+}
+__global__ __launch_bounds__(256) void pack_owned_kernel(const float* __restrict__ master, const long long* __restrict__ idx,
+                                                         const unsigned char* __restrict__ own, float* __restrict__ out,
+                                                         long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    out[i] = own[i] ? master[idx[i]] : 0.f;
+}
+__global__ __launch_bounds__(256) void scatter_values_kernel(float* __restrict__ master, const long long* __restrict__ idx,
+                                                             const float* __restrict__ vals, long long n) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+    master[idx[i]] = vals[i];
+}
+// ranges: device table of nranges [lo, hi) pairs (int64, multiples of 8, max_len = the longest one)
+extern "C" int ddl_cast_ranges(const void* shadow, float* master, const long long* ranges, int nranges, long long max_len,
+                               void* stream) {
+  if (nranges <= 0 || max_len <= 0) return 0;
+  if (nranges > 65535 || max_len % 8 != 0) return -1;
+  hipLaunchKernelGGL(cast_ranges_kernel, dim3(grid_for(max_len / 8, 256), nranges), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)shadow, master, ranges);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_pack_owned(const float* master, const long long* idx, const void* own, float* out, long long n,
+                              void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pack_owned_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, master, idx,
+                     (const unsigned char*)own, out, n);
+  return (int)hipGetLastError();
+}
+extern "C" int ddl_scatter_values(float* master, const long long* idx, const float* vals, long long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(scatter_values_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, master, idx, vals, n);
+  return (int)hipGetLastError();
+}
+
 // ---------------------------------------------------------------- channel windows of NHWC buffers
 // dst[row][0..C) = src[row][0..C) for two [M][*] bf16 buffers with independent row pitches (elements): packs a dense
 // tensor into a channel window of a wider buffer (dense-block feature map) or extracts a window into a dense tensor.

@@ -27,11 +27,14 @@ __global__ void rng_advance_kernel(unsigned long long* __restrict__ state) {
 
 // ---------------------------------------------------------------- forward epilogue
 // y[r][c] = drop(relu(acc[r][c] + bias[c])) as bf16; rows >= M_valid and the accumulator's padding are not written.
+// With n8_clear > 0 the accumulator ([n8_clear * 8] floats, >= the rows read) is ZEROED behind the read: a persistent
+// accumulator is handed back ready for the next split-M GEMM, with no memset launch between them.
 // Dropout keeps an element with probability 1 - p and scales it by 1/(1-p); the mask is NOT stored: a kept, live
 // element is exactly one with y > 0, which is all the backward needs.
-__global__ __launch_bounds__(256) void linear_epilogue_kernel(const float* __restrict__ acc, const float* __restrict__ bias,
-                                                              bf16_t* __restrict__ y, long long n8, int N, int relu,
-                                                              float drop_p, const unsigned long long* __restrict__ rng) {
+__global__ __launch_bounds__(256) void linear_epilogue_kernel(float* __restrict__ acc, const float* __restrict__ bias,
+                                                              bf16_t* __restrict__ y, long long n8, long long n8_clear, int N,
+                                                              int relu, float drop_p,
+                                                              const unsigned long long* __restrict__ rng) {
   const int n8row = N / 8;
   unsigned long long key = 0ull;
   unsigned thresh = 0u;
@@ -41,10 +44,20 @@ __global__ __launch_bounds__(256) void linear_epilogue_kernel(const float* __res
     thresh = (unsigned)(drop_p * 65536.f);                                       // 16-bit uniform per element
     scale = 1.f / (1.f - drop_p);
   }
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+  const long long n8_all = n8 > n8_clear ? n8 : n8_clear;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8_all; i += (long long)gridDim.x * 256) {
+    if (i >= n8) {                                                               // padding rows: only cleared
+      *reinterpret_cast<f32x4*>(acc + i * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(acc + i * 8 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     const int c = (int)(i % n8row) * 8;
     const f32x4 a = *reinterpret_cast<const f32x4*>(acc + i * 8);
     const f32x4 b = *reinterpret_cast<const f32x4*>(acc + i * 8 + 4);
+    if (i < n8_clear) {
+      *reinterpret_cast<f32x4*>(acc + i * 8) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(acc + i * 8 + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     if (bias != nullptr) {
 #pragma unroll
@@ -141,14 +154,25 @@ __global__ __launch_bounds__(256) void transpose_pad_kernel(const TIN* __restric
 }
 
 // ---------------------------------------------------------------- fp32 [M][Np] -> bf16 [M][N] (drop padding columns)
-__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ acc, bf16_t* __restrict__ out, long long n8,
-                                                        int N8, long long acc_pitch) {
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+// n8_clear > 0 (needs acc_pitch == N): the accumulator's first n8_clear * 8 floats are zeroed behind the read.
+__global__ __launch_bounds__(256) void cast_rows_kernel(float* __restrict__ acc, bf16_t* __restrict__ out, long long n8,
+                                                        long long n8_clear, int N8, long long acc_pitch) {
+  const long long n8_all = n8 > n8_clear ? n8 : n8_clear;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8_all; i += (long long)gridDim.x * 256) {
     const long long r = i / N8;
     const int c = (int)(i - r * N8) * 8;
-    const float* src = acc + r * acc_pitch + c;
+    float* src = acc + r * acc_pitch + c;
+    if (i >= n8) {
+      *reinterpret_cast<f32x4*>(src) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(src + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      continue;
+    }
     const f32x4 a = *reinterpret_cast<const f32x4*>(src);
     const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+    if (i < n8_clear) {
+      *reinterpret_cast<f32x4*>(src) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(src + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const float f[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
     *reinterpret_cast<u32x4*>(out + i * 8) = pack8(f);
   }
@@ -181,14 +205,16 @@ __global__ __launch_bounds__(1024) void l1_loss_kernel(const T* __restrict__ pre
 }
 
 // ================================================================ C ABI
-extern "C" int ddl_linear_epilogue(const float* acc, const float* bias, void* y, int M, int N, int relu, float drop_p,
-                                   const void* rng_state, void* stream) {
+// clear_rows > 0: zero the accumulator's first clear_rows rows (>= M: its padding rows too) behind the read.
+extern "C" int ddl_linear_epilogue(float* acc, const float* bias, void* y, int M, int N, int relu, float drop_p,
+                                   const void* rng_state, int clear_rows, void* stream) {
   if (M <= 0 || N <= 0 || N % 8 != 0 || drop_p < 0.f || drop_p >= 1.f) return -1;
   if (drop_p > 0.f && rng_state == nullptr) return -2;
-  const long long n8 = (long long)M * (N / 8);
+  if (clear_rows != 0 && clear_rows < M) return -3;
+  const long long n8 = (long long)M * (N / 8), n8c = (long long)clear_rows * (N / 8);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(linear_epilogue_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, st, acc, bias, (bf16_t*)y, n8, N, relu,
-                     drop_p, (const unsigned long long*)rng_state);
+  hipLaunchKernelGGL(linear_epilogue_kernel, dim3(grid_for(n8 > n8c ? n8 : n8c, 256)), dim3(256), 0, st, acc, bias,
+                     (bf16_t*)y, n8, n8c, N, relu, drop_p, (const unsigned long long*)rng_state);
   if (drop_p > 0.f)
     hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)rng_state);
   return (int)hipGetLastError();
@@ -235,11 +261,13 @@ extern "C" int ddl_transpose_pad(const void* in, int in_is_f32, void* out, int R
 }
 
 // acc fp32 [M][acc_pitch] -> out bf16 [M][N] (N % 8 == 0, N <= acc_pitch)
-extern "C" int ddl_cast_rows(const float* acc, void* out, int M, int N, long long acc_pitch, void* stream) {
+// clear_rows > 0 (needs acc_pitch == N, clear_rows >= M): zero the accumulator's first clear_rows rows behind the read.
+extern "C" int ddl_cast_rows(float* acc, void* out, int M, int N, long long acc_pitch, int clear_rows, void* stream) {
   if (M <= 0 || N <= 0 || N % 8 != 0 || acc_pitch < N || acc_pitch % 4 != 0) return -1;
-  const long long n8 = (long long)M * (N / 8);
-  hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for(n8, 256)), dim3(256), 0, (hipStream_t)stream, acc, (bf16_t*)out, n8,
-                     N / 8, acc_pitch);
+  if (clear_rows != 0 && (clear_rows < M || acc_pitch != N)) return -3;
+  const long long n8 = (long long)M * (N / 8), n8c = (long long)clear_rows * (N / 8);
+  hipLaunchKernelGGL(cast_rows_kernel, dim3(grid_for(n8 > n8c ? n8 : n8c, 256)), dim3(256), 0, (hipStream_t)stream, acc,
+                     (bf16_t*)out, n8, n8c, N / 8, acc_pitch);
   return (int)hipGetLastError();
 }
 

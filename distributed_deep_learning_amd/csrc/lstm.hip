@@ -250,6 +250,50 @@ __global__ __launch_bounds__(H / 16 * 64) void lstm_bwd_kernel(
   }
 }
 
+// ---------------------------------------------------------------- input gradient: dx[M][N] = dG[M][K] @ W_ih[K][N]
+// A row GEMM with a huge M (= B*T), a short reduction (K = 4H <= 512) and a narrow output (N = I <= 128).  Operands
+// in the MFMA's natural form: both with the reduction index contiguous - dG as it is, the weight as its [N][K]
+// transpose (the arena's twin).  A wave owns 32 rows and ALL N columns: the row fragments come straight from global
+// memory, once; the weight (<= 128 KiB) is re-read by every wave and stays in L2.  The weight is the MFMA's A operand
+// and the rows its B operand, so a lane ends with 4 consecutive COLUMNS of one row: one 8-byte store.
+template <int NT>
+__global__ __launch_bounds__(256) void rows_gemm_nt_kernel(const bf16_t* __restrict__ a, const bf16_t* __restrict__ bt,
+                                                           bf16_t* __restrict__ out, int M, int K) {
+  constexpr int N = NT * 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  if (m0 >= M) return;
+  const int r16 = lane & 15, q4 = lane >> 4;
+  const int row0 = min(m0 + r16, M - 1), row1 = min(m0 + 16 + r16, M - 1);
+  const bf16_t* a0 = a + (size_t)row0 * K + q4 * 8;
+  const bf16_t* a1 = a + (size_t)row1 * K + q4 * 8;
+  const bf16_t* bp = bt + (size_t)r16 * K + q4 * 8;
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) acc[0][i] = acc[1][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int k = 0; k < K; k += 32) {
+    const bf16x8 x0 = *reinterpret_cast<const bf16x8*>(a0 + k);
+    const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(a1 + k);
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(bp + (size_t)i * 16 * K + k);
+      acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x0, acc[0][i], 0, 0, 0);
+      acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x1, acc[1][i], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int row = m0 + h * 16 + r16;
+    if (row >= M) continue;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+      float f[4] = {acc[h][i][0], acc[h][i][1], acc[h][i][2], acc[h][i][3]};
+      *reinterpret_cast<u32x2*>(out + (size_t)row * N + i * 16 + q4 * 4) = pack4(f);
+    }
+  }
+}
+
 template <int H, int I>
 int launch_fwd(const void* x, long long x_sb, long long x_st, const void* w_ih, const void* w_hh, const void* bias,
                void* hseq, void* cseq, void* gates, int B, int T, int save, hipStream_t st) {
@@ -301,6 +345,22 @@ int ddl_lstm_bwd(const void* dout, long long d_sb, long long d_st, const void* g
   hipStream_t st = (hipStream_t)stream;
   if (H == 128) return launch_bwd<128>(dout, d_sb, d_st, gates, cseq, w_hhT, dG, dh0, dc0, B, T, st);
   return launch_bwd<64>(dout, d_sb, d_st, gates, cseq, w_hhT, dG, dh0, dc0, B, T, st);
+}
+
+// out[M][N] (bf16) = a[M][K] @ bt[N][K]^T; K a multiple of 32, N one of 32 / 64 / 128 (the LSTM input widths).
+int ddl_rows_gemm_nt(const void* a, const void* bt, void* out, int M, int K, int N, void* stream) {
+  if (M <= 0 || K <= 0 || (K % 32) != 0 || !(N == 32 || N == 64 || N == 128)) return -1;
+  if (a == nullptr || bt == nullptr || out == nullptr) return -2;
+  if (((((uintptr_t)a) | ((uintptr_t)bt)) & 15) != 0 || (((uintptr_t)out) & 7) != 0) return -3;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((M + 127) / 128), block(256);
+  if (N == 32)
+    hipLaunchKernelGGL((rows_gemm_nt_kernel<2>), grid, block, 0, st, (const bf16_t*)a, (const bf16_t*)bt, (bf16_t*)out, M, K);
+  else if (N == 64)
+    hipLaunchKernelGGL((rows_gemm_nt_kernel<4>), grid, block, 0, st, (const bf16_t*)a, (const bf16_t*)bt, (bf16_t*)out, M, K);
+  else
+    hipLaunchKernelGGL((rows_gemm_nt_kernel<8>), grid, block, 0, st, (const bf16_t*)a, (const bf16_t*)bt, (bf16_t*)out, M, K);
+  return (int)hipGetLastError();
 }
 
 }  // extern "C"

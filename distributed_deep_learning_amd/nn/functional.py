@@ -765,9 +765,13 @@ class LinearAct(torch.autograd.Function):
         if fin != in_p:                                    # feature count not a multiple of 8 (LeNet's 84): zero columns
             x = torch.nn.functional.pad(x, (0, in_p - fin))
         xt = K.transpose_pad(x, Bp)                        # [in_p, Bp]: the reduction index leads
-        acc = torch.zeros((Bp, out_p), dtype=torch.float32, device=x.device)
-        K.gemm_tn(xt, w16_t, acc)
-        y = K.linear_epilogue(acc, bias_p, Bp, relu=relu, drop_p=drop_p)
+        acc = K.zero_accumulator(Bp, out_p, x.device)      # persistent, handed back zeroed by the epilogue
+        try:
+            K.gemm_tn(xt, w16_t, acc)
+            y = K.linear_epilogue(acc, bias_p, Bp, relu=relu, drop_p=drop_p, clear=True)
+        except Exception:
+            K.drop_accumulators()
+            raise
         need_w = ctx.needs_input_grad[1]
         xs = None
         if need_w:                                         # wgrad operand: bf16 [Bp, in_p], batch rows zero-padded
@@ -812,9 +816,13 @@ class LinearAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             gt = K.transpose_pad(g, Bp)                    # [out_p, Bp]
-            acc = torch.zeros((Bp, in_p), dtype=torch.float32, device=g.device)
-            K.gemm_tn(gt, w16, acc)
-            dx = K.cast_rows(acc, B, in_p)
+            acc = K.zero_accumulator(Bp, in_p, g.device)
+            try:
+                K.gemm_tn(gt, w16, acc)
+                dx = K.cast_rows(acc, B, in_p, clear=True)
+            except Exception:
+                K.drop_accumulators()
+                raise
             if in_p != fin:
                 dx = dx[:, :fin]
         dw = None

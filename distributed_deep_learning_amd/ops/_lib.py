@@ -25,10 +25,14 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 _SIGS = {
     "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 13 + [_vp],
     "ddl_conv_fwd_inbn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp],
+    "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp, _ll, _vp],
+    "ddl_conv_wgrad_plan": [_i] * 11,
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_spin": [_ll, _vp],
     "ddl_stream_proxy": [_vp, _ll, C.c_int, C.c_int, _vp],
+    "ddl_cast_ranges": [_vp, _vp, _vp, _i, _ll, _vp],
+    "ddl_pack_owned": [_vp, _vp, _vp, _vp, _ll, _vp],
+    "ddl_scatter_values": [_vp, _vp, _vp, _ll, _vp],
     "ddl_bn_slots": [],
     "ddl_slab_fold": [_vp, _i, _vp, _i, _vp],
     "ddl_bn_stats": [_vp, _vp, _i, _i, _vp],
@@ -68,10 +72,10 @@ _SIGS = {
     "ddl_flat_sumsq": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_flat_sgd": [_vp] * 9 + [_i, _i, _i, _vp],
     "ddl_flat_adam": [_vp] * 8 + [_i, _i, _i, _vp],
-    "ddl_linear_epilogue": [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _vp],
+    "ddl_linear_epilogue": [_vp, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp],
     "ddl_linear_bwd_gate": [_vp, _vp, _vp, _vp, _i, _i, _f, _i, _i, _vp],
     "ddl_transpose_pad": [_vp, _i, _vp, _i, _i, _i, _ll, _vp],
-    "ddl_cast_rows": [_vp, _vp, _i, _i, _ll, _vp],
+    "ddl_cast_rows": [_vp, _vp, _i, _i, _ll, _i, _vp],
     "ddl_l1_loss": [_vp, _i, _vp, _vp, _vp, _ll, _vp],
     "ddl_conv1d_k1_relu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "ddl_conv1d_k1_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -92,7 +96,11 @@ _SIGS = {
     "ddl_lstm_supported": [_i, _i],
     "ddl_lstm_fwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ddl_lstm_bwd": [_vp, _ll, _ll, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "ddl_rows_gemm_nt": [_vp, _vp, _vp, _i, _i, _i, _vp],
 }
+
+
+_LONG_RESULT = {"ddl_conv_wgrad_plan"}
 
 
 def _load():
@@ -104,7 +112,7 @@ def _load():
         for name, argtypes in _SIGS.items():
             fn = getattr(lib, name)
             fn.argtypes = argtypes
-            fn.restype = _i
+            fn.restype = _ll if name in _LONG_RESULT else _i
         _lib = lib
     except Exception as e:  # noqa: BLE001 - recorded and re-raised by require()
         _load_error = e

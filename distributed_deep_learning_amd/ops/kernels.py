@@ -10,6 +10,8 @@ Conventions
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import _lib
@@ -343,6 +345,55 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
     return dx
 
 
+_WGRAD_PLANS: dict = {}
+# 0 restores the float-atomic meeting of the split-M partial tiles (debug knob, docs/STATUS.md "debug switches")
+_WGRAD_REPRODUCIBLE = os.environ.get("DDL_WGRAD_ATOMICS", "0") != "1"
+
+
+_WGRAD_PENDING: dict = {}        # raw stream -> workspace of the deferred launch whose slabs are still unreduced
+
+
+def _wgrad_workspace(lib, geom, device):
+    """Scratch for the split-M partial tiles of one filter-gradient launch (``csrc/conv_wgrad.hip``: slabs + ordered
+    reduce = bit-reproducible gradients).  Sized by the launcher's own plan, cached per geometry; the buffer comes from
+    the caching allocator on the CURRENT stream, so consecutive launches reuse blocks in stream order.
+
+    Inside the wgrad side-stream fork (``ops.streams``) the launch is DEFERRED: its slabs are reduced by the next filter
+    gradient on that stream (no separate launch between two of them) or by :func:`wgrad_flush`, which the join and the
+    reducer's bucket launch call; the workspace is kept alive here until then.
+    Returns ``(tensor or None, elements, defer flag, raw stream)``."""
+    st = stream_ptr()
+    if not _WGRAD_REPRODUCIBLE:
+        return None, 0, 0, st
+    need = _WGRAD_PLANS.get(geom)
+    if need is None:
+        need = int(lib.ddl_conv_wgrad_plan(*geom))
+        if need < 0:
+            raise ValueError(f"conv wgrad: unsupported problem {geom} (rc {need})")
+        _WGRAD_PLANS[geom] = need
+    from . import streams
+    defer = int(streams.in_fork(device, st))
+    ws = torch.empty(need, dtype=torch.float32, device=device) if need > 0 else None
+    return ws, need, defer, st
+
+
+def _wgrad_launched(st, ws, defer) -> None:
+    """After a filter-gradient launch on raw stream ``st``: the launch has reduced whatever was pending there; its own
+    slabs are pending now when it was deferred."""
+    if defer and ws is not None:
+        _WGRAD_PENDING[st] = ws
+    else:
+        _WGRAD_PENDING.pop(st, None)
+
+
+def wgrad_flush() -> None:
+    """Reduce the slabs a deferred filter gradient left on the CURRENT stream (no-op without one)."""
+    st = stream_ptr()
+    if st in _WGRAD_PENDING:
+        check(_lib.require().ddl_conv_wgrad_flush(st), "conv_wgrad_flush")
+        del _WGRAD_PENDING[st]
+
+
 def conv2d_wgrad(dy, x, R, S, stride=1, pad=0, out=None):
     """Returns dw as an fp32 tensor of logical shape ``[K,C,R,S]`` with channels-last (KRSC) strides.
     ``out``: optional fp32 ``[K,C,R,S]`` channels-last tensor to ACCUMULATE into (e.g. the arena gradient view)."""
@@ -354,16 +405,19 @@ def conv2d_wgrad(dy, x, R, S, stride=1, pad=0, out=None):
     N2, Cc, H, W = x.shape
     if N2 != N or conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
         raise ValueError("conv2d_wgrad: geometry mismatch")
+    ws, ws_n, defer, st = _wgrad_workspace(lib, (N, H, W, Cc, K, P, Q, R, S, stride, pad), x.device)
     if out is not None:
         if (out.dtype != torch.float32 or tuple(out.shape) != (K, Cc, R, S)
                 or not out.permute(0, 2, 3, 1).is_contiguous()):
             raise ValueError("conv2d_wgrad: out must be fp32 [K,C,R,S] with channels-last (KRSC) strides")
-        check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(out), N, H, W, Cc, K, P, Q, R, S, stride, pad, stream_ptr()),
-              "conv2d_wgrad")
+        check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(out), N, H, W, Cc, K, P, Q, R, S, stride, pad, ptr(ws), ws_n,
+                                 defer, st), "conv2d_wgrad")
+        _wgrad_launched(st, ws, defer)
         return out
     dw = torch.zeros((K, R, S, Cc), dtype=torch.float32, device=x.device)
-    check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(dw), N, H, W, Cc, K, P, Q, R, S, stride, pad, stream_ptr()),
-          "conv2d_wgrad")
+    check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(dw), N, H, W, Cc, K, P, Q, R, S, stride, pad, ptr(ws), ws_n,
+                             0, st), "conv2d_wgrad")
+    _wgrad_launched(st, ws, 0)
     return dw.permute(0, 3, 1, 2)
 
 
@@ -700,6 +754,40 @@ def bias_grad(dy):
     return db
 
 
+def cast_ranges(shadow: torch.Tensor, master: torch.Tensor, ranges: torch.Tensor, max_len: int) -> None:
+    """``master[lo:hi] = float(shadow[lo:hi])`` for every ``[lo, hi)`` row of the int64 device table ``ranges`` - ONE
+    launch (the PS / ZeRO-1 pull refreshes the fp32 masters of all foreign ranges with it)."""
+    lib = _lib.require()
+    if ranges.dtype != torch.int64 or ranges.dim() != 2 or ranges.shape[1] != 2 or not ranges.is_contiguous():
+        raise ValueError("cast_ranges: ranges must be a contiguous int64 [n, 2] tensor")
+    if shadow.dtype != BF16 or master.dtype != torch.float32 or shadow.numel() != master.numel():
+        raise ValueError("cast_ranges: bf16 shadow and fp32 master of the same length")
+    _lib.check_device(master, "cast_ranges")
+    check(lib.ddl_cast_ranges(ptr(shadow), ptr(master), ptr(ranges), ranges.shape[0], int(max_len), stream_ptr()), "cast_ranges")
+
+
+def pack_owned(master: torch.Tensor, idx: torch.Tensor, own: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """``out[i] = master[idx[i]] if own[i] else 0`` (fp32; ``idx`` int64, ``own`` bool / uint8) in one launch."""
+    lib = _lib.require()
+    n = idx.numel()
+    if out is None:
+        out = torch.empty(n, dtype=torch.float32, device=master.device)
+    if idx.dtype != torch.int64 or own.numel() != n or own.element_size() != 1 or out.numel() != n or master.dtype != torch.float32:
+        raise ValueError("pack_owned: bad operands")
+    _lib.check_device(master, "pack_owned")
+    check(lib.ddl_pack_owned(ptr(master), ptr(idx), ptr(own), ptr(out), n, stream_ptr()), "pack_owned")
+    return out
+
+
+def scatter_values(master: torch.Tensor, idx: torch.Tensor, vals: torch.Tensor) -> None:
+    """``master[idx[i]] = vals[i]`` (fp32, unique indices) in one launch."""
+    lib = _lib.require()
+    if idx.dtype != torch.int64 or vals.numel() != idx.numel() or vals.dtype != torch.float32 or master.dtype != torch.float32:
+        raise ValueError("scatter_values: bad operands")
+    _lib.check_device(master, "scatter_values")
+    check(lib.ddl_scatter_values(ptr(master), ptr(idx), ptr(vals), idx.numel(), stream_ptr()), "scatter_values")
+
+
 def cast_f32_bf16(src: torch.Tensor, dst: torch.Tensor | None = None):
     lib = _lib.require()
     n = src.numel()
@@ -770,7 +858,10 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor
         raise ValueError("gemm_tn: operands must be contiguous [M, Ka] / [M, Cb] with Ka, Cb multiples of 8")
     if out.dtype != torch.float32 or tuple(out.shape) != (Ka, Cb) or not out.is_contiguous():
         raise ValueError("gemm_tn: out must be a contiguous fp32 [Ka, Cb] tensor")
-    check(lib.ddl_conv_wgrad(ptr(a), ptr(b), ptr(out), M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0, stream_ptr()), "gemm_tn")
+    ws, ws_n, defer, st = _wgrad_workspace(lib, (M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0), a.device)
+    check(lib.ddl_conv_wgrad(ptr(a), ptr(b), ptr(out), M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0, ptr(ws), ws_n, defer, st),
+          "gemm_tn")
+    _wgrad_launched(st, ws, defer)
     return out
 
 
@@ -801,8 +892,31 @@ def rng_state(device) -> torch.Tensor:
     return st
 
 
-def linear_epilogue(acc: torch.Tensor, bias, rows: int, relu: bool = False, drop_p: float = 0.0) -> torch.Tensor:
-    """fp32 accumulator ``[Mp, N]`` -> bf16 ``[rows, N]``: ``drop(relu(acc + bias))`` (``csrc/linear.hip``)."""
+_ACCUMULATORS: dict = {}
+
+
+def zero_accumulator(rows: int, cols: int, device) -> torch.Tensor:
+    """A persistent fp32 ``[rows, cols]`` GEMM accumulator that is ALWAYS ZERO between uses: whoever takes it runs the
+    split-M GEMM into it and then reads it out with ``linear_epilogue(..., clear=True)`` / ``cast_rows(..., clear=True)``,
+    which zero it behind the read - no allocation and no memset launch per GEMM.  One per shape and device; all users are
+    ordered on the device's current stream.  :func:`drop_accumulators` forgets them (after a failed launch)."""
+    key = (rows, cols, device.type, device.index)
+    acc = _ACCUMULATORS.get(key)
+    if acc is None:
+        if torch.cuda.is_current_stream_capturing():          # a graph's private pool must not own a persistent buffer
+            return torch.zeros((rows, cols), dtype=torch.float32, device=device)
+        acc = _ACCUMULATORS[key] = torch.zeros((rows, cols), dtype=torch.float32, device=device)
+    return acc
+
+
+def drop_accumulators() -> None:
+    _ACCUMULATORS.clear()
+
+
+def linear_epilogue(acc: torch.Tensor, bias, rows: int, relu: bool = False, drop_p: float = 0.0,
+                    clear: bool = False) -> torch.Tensor:
+    """fp32 accumulator ``[Mp, N]`` -> bf16 ``[rows, N]``: ``drop(relu(acc + bias))`` (``csrc/linear.hip``); ``clear``
+    zeroes the whole accumulator behind the read."""
     lib = _lib.require()
     Mp, N = acc.shape
     if acc.dtype != torch.float32 or not acc.is_contiguous() or N % 8 or rows > Mp:
@@ -812,8 +926,8 @@ def linear_epilogue(acc: torch.Tensor, bias, rows: int, relu: bool = False, drop
     _lib.check_device(acc, "linear_epilogue")
     y = torch.empty((rows, N), dtype=BF16, device=acc.device)
     st = rng_state(acc.device) if drop_p > 0.0 else None
-    check(lib.ddl_linear_epilogue(ptr(acc), ptr(bias), ptr(y), rows, N, int(relu), float(drop_p), ptr(st), stream_ptr()),
-          "linear_epilogue")
+    check(lib.ddl_linear_epilogue(ptr(acc), ptr(bias), ptr(y), rows, N, int(relu), float(drop_p), ptr(st),
+                                  Mp if clear else 0, stream_ptr()), "linear_epilogue")
     return y
 
 
@@ -841,13 +955,17 @@ def linear_bwd_gate(dy: torch.Tensor, y, scale: float = 1.0, grad_out=None, want
     return g, db
 
 
-def cast_rows(acc: torch.Tensor, rows: int, cols: int) -> torch.Tensor:
-    """fp32 ``[Mp, Np]`` accumulator -> bf16 ``[rows, cols]`` (drops the padding; ``cols % 8 == 0``)."""
+def cast_rows(acc: torch.Tensor, rows: int, cols: int, clear: bool = False) -> torch.Tensor:
+    """fp32 ``[Mp, Np]`` accumulator -> bf16 ``[rows, cols]`` (drops the padding; ``cols % 8 == 0``); ``clear`` (needs
+    ``cols == Np``) zeroes the whole accumulator behind the read."""
     lib = _lib.require()
     if acc.dtype != torch.float32 or not acc.is_contiguous() or cols % 8 or rows > acc.shape[0] or cols > acc.shape[1]:
         raise ValueError("cast_rows: bad shapes")
+    if clear and cols != acc.shape[1]:
+        raise ValueError("cast_rows: clear needs cols == the accumulator's width")
     out = torch.empty((rows, cols), dtype=BF16, device=acc.device)
-    check(lib.ddl_cast_rows(ptr(acc), ptr(out), rows, cols, acc.shape[1], stream_ptr()), "cast_rows")
+    check(lib.ddl_cast_rows(ptr(acc), ptr(out), rows, cols, acc.shape[1], acc.shape[0] if clear else 0, stream_ptr()),
+          "cast_rows")
     return out
 
 
@@ -952,6 +1070,21 @@ def mlp_bwd(dout, out, acts, weights, dweights, dbiases, relu_last=False, want_d
 def lstm_supported(hidden: int, inputs: int) -> bool:
     """Shapes with a compiled instance of the fused LSTM layer (constants mirrored from csrc/lstm.hip)."""
     return hidden in (64, 128) and inputs in (32, 64, 128)
+
+
+def rows_gemm_nt(a: torch.Tensor, bt: torch.Tensor) -> torch.Tensor:
+    """bf16 ``[M, N] = a[M, K] @ bt[N, K]^T`` for a huge ``M``, ``K % 32 == 0`` and ``N`` in 32 / 64 / 128: the LSTM
+    input gradient ``dG @ W_ih`` (``csrc/lstm.hip``), ``bt`` being the weight's ``[in, 4H]`` transpose."""
+    lib = _lib.require()
+    _chk_act(a, "rows_gemm_nt")
+    _chk_act(bt, "rows_gemm_nt")
+    M, Kr = a.shape
+    N, K2 = bt.shape
+    if K2 != Kr or Kr % 32 or N not in (32, 64, 128) or not a.is_contiguous() or not bt.is_contiguous():
+        raise ValueError("rows_gemm_nt: need contiguous a [M, K], bt [N, K] with K % 32 == 0 and N in (32, 64, 128)")
+    out = torch.empty((M, N), dtype=BF16, device=a.device)
+    check(lib.ddl_rows_gemm_nt(ptr(a), ptr(bt), ptr(out), M, Kr, N, stream_ptr()), "rows_gemm_nt")
+    return out
 
 
 def lstm_fwd(x, w_ih, w_hh, bias, h0=None, c0=None, save=True):

@@ -12,7 +12,7 @@ Ordering rules, all enforced here:
   caching allocator defers every such block's reuse to its own event polling, the main stream runs ahead of it, and
   the pool answers with fresh ``hipMalloc`` calls in steady state (measured on ResNet-50, B=512: 200-320 device
   allocations inside 20 timed steps, 135 GB reserved for a ~45 GB working set, and in a quarter of all runs one step
-  stalled for 1.2-2.0 s — `docs/STATUS.md`);
+  stalled for 1.2-2.0 s — `docs/STATUS.md`); that policy is gone, there is no switch that brings it back;
 * join: the first fork inside a backward pass queues an autograd-engine callback that makes the main stream wait
   for the side stream when the pass ends, so ``loss.backward()`` keeps its usual meaning (gradients are ordered
   before anything later on the current stream); :func:`join` does the same on demand (optimizer step);
@@ -32,10 +32,6 @@ _ENABLED = os.environ.get("DDL_WGRAD_STREAM", "1") != "0"
 _side: dict[int, torch.cuda.Stream] = {}
 _dirty: set[int] = set()
 _callback_queued = False
-_LIFETIME = os.environ.get("DDL_SIDE_LIFETIME", "hold")      # hold | join | record_stream (the old policy), for A/B runs
-_RECORD_STREAM = _LIFETIME == "record_stream"
-_KEEP_JOINS = int(os.environ.get("DDL_SIDE_KEEP_JOINS", "0"))     # experiment: release operands only k joins later
-_grave: list = []
 _held: dict[int, list] = {}          # device -> [(event or None, operands)] still (possibly) read on the side stream
 
 
@@ -142,12 +138,6 @@ def fork(*operands: torch.Tensor):
     side.wait_stream(main)
     capturing = torch.cuda.is_current_stream_capturing()
     held = _held.setdefault(dev.index, [])
-    if _RECORD_STREAM:
-        for t in operands:
-            t.record_stream(side)
-        capturing, operands = True, ()
-    elif _LIFETIME == "join":
-        capturing = True                  # no events: everything is held until the join
     if not capturing:
         while held and held[0][0] is not None and held[0][0].query():    # side-stream work finished: operands may go
             held.pop(0)
@@ -175,11 +165,7 @@ def join() -> None:
         torch.cuda.current_stream(index).wait_stream(_side[index])
         # everything enqueued on the current stream from here on is ordered behind the side stream: the operands'
         # memory may be reused by it
-        gone = _held.pop(index, None)
-        if _KEEP_JOINS > 0 and gone:
-            _grave.append(gone)
-            while len(_grave) > _KEEP_JOINS:
-                _grave.pop(0)
+        _held.pop(index, None)
     _dirty.clear()
 
 

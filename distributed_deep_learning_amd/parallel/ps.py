@@ -38,6 +38,7 @@ class ShardedDataParallel(DistributedDataParallel):
             kw["mode"] = "ps"
         super().__init__(module, *args, **kw)
         self._small_idx: Optional[torch.Tensor] = None
+        self._foreign_max = 0
         self._optimizer = None
         self.bf16_pull = self.dist and self.arena.shadow is not None and self.on_gpu
         if self.bf16_pull:
@@ -49,14 +50,22 @@ class ShardedDataParallel(DistributedDataParallel):
             return None
         return [self.arena.shard_range(b, self.rank, self.world) for b in range(len(self.arena.buckets))]
 
+    @staticmethod
+    def consumed_in_fp32(p) -> bool:
+        """True for a parameter some kernel reads from the fp32 MASTER: every tensor that has no bf16 shadow pair
+        (``_ddl_shadow_t``: conv filters and Linear / LSTM weights with both sides % 8 == 0 are consumed through it).
+        That is all 1-D tensors (BN affine, biases), the 3-channel stem filter, the Conv1d front of the LSTM workload,
+        Linear weights with a ragged side.  They must be identical on every replica, so they travel exactly."""
+        return getattr(p, "_ddl_shadow_t", None) is None
+
     def _build_small_table(self) -> None:
-        """Index tables of the 1-D tensors (consumed in fp32 by the kernels): positions in the arena, and a 0/1 mask of
-        the positions this rank owns.  ~53k elements for ResNet-50."""
+        """Index tables of the tensors consumed in fp32: positions in the arena, a 0/1 mask of the positions this rank
+        owns (~63k elements for ResNet-50), and the table of the foreign ranges (everything other ranks own)."""
         a = self.arena
         idx, own = [], []
         ranges = self.owned_ranges() or []
         for p, s in zip(a.params, a.segments):
-            if p.dim() > 1:
+            if not self.consumed_in_fp32(p):
                 continue
             lo, hi = ranges[s.bucket]
             r = torch.arange(s.offset, s.offset + s.numel, dtype=torch.int64)
@@ -65,6 +74,13 @@ class ShardedDataParallel(DistributedDataParallel):
         if idx:
             self._small_idx = torch.cat(idx).to(a.device)
             self._small_own = torch.cat(own).to(a.device)
+            self._small_buf = torch.empty(self._small_idx.numel(), dtype=torch.float32, device=a.device)
+        foreign = []
+        for b, (lo, hi) in enumerate(ranges):
+            bk = a.buckets[b]
+            foreign += [r for r in ((bk.lo, lo), (hi, bk.hi)) if r[1] > r[0]]
+        self._foreign = torch.tensor(foreign, dtype=torch.int64).reshape(-1, 2).to(a.device)
+        self._foreign_max = max((hi - lo for lo, hi in foreign), default=0)
 
     # ------------------------------------------------------------------ push
     def _launch_collective(self, b: int, g: torch.Tensor) -> None:
@@ -137,21 +153,17 @@ class ShardedDataParallel(DistributedDataParallel):
         values, zero elsewhere), everything else from the gathered bf16 shadow."""
         a = self.arena
         from ..ops import kernels as K
-        for b in range(len(a.buckets)):
-            bk = a.buckets[b]
-            lo, hi = a.shard_range(b, self.rank, self.world)
-            if lo > bk.lo:
-                K.cast_bf16_f32(a.shadow[bk.lo:lo], a.master[bk.lo:lo])
-            if hi < bk.hi:
-                K.cast_bf16_f32(a.shadow[hi:bk.hi], a.master[hi:bk.hi])
-        if self._small_idx is not None:
-            vals = a.master.index_select(0, self._small_idx)
-            small = torch.where(self._small_own, vals, torch.zeros_like(vals))
-            if self.ncomm is not None:
-                self.ncomm.all_reduce(small, average=False).wait()
-            else:
-                td.all_reduce(small, op=td.ReduceOp.SUM, group=self.pg)
-            a.master.index_copy_(0, self._small_idx, small)
+        small = None
+        if self._small_idx is not None:                       # before the cast below overwrites nothing we own: owned
+            small = K.pack_owned(a.master, self._small_idx, self._small_own, self._small_buf)     # values, 0 elsewhere
+            h = self.ncomm.all_reduce(small, average=False) if self.ncomm is not None else \
+                self._all_reduce_sum_async(small, ("small",))
+        if self._foreign_max > 0:                             # one launch for every foreign range, beside the all-reduce
+            K.cast_ranges(a.shadow, a.master, self._foreign, self._foreign_max)
+        if small is not None:
+            if h is not None:
+                h.wait()
+            K.scatter_values(a.master, self._small_idx, small)
 
     def gather_master(self) -> None:
         """Exact fp32 masters of every shard on every rank (checkpoint time)."""

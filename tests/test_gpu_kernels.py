@@ -352,6 +352,29 @@ print("PATCH_OK")
     assert r.returncode == 0 and "PATCH_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,C,H,K,R,stride,pad", [(32, 64, 56, 64, 3, 1, 1), (16, 16, 115, 64, 4, 1, 0), (24, 512, 7, 512, 3, 1, 1),
+                                                  (32, 256, 14, 1024, 1, 1, 0), (20, 128, 28, 128, 3, 2, 1)])
+def test_wgrad_is_bit_reproducible_and_accumulates(N, C, H, K, R, stride, pad):
+    """The split-M partial tiles of a filter gradient meet in slabs + an ordered reduce (csrc/conv_wgrad.hip), not in
+    float atomics: two launches on the same operands agree to the BIT, for every tile family (64-channel 3x3 with
+    hundreds of splits, the folded stem tile, wide late-layer tiles, plain 1x1, strided), and ``out=`` is accumulated
+    into."""
+    from distributed_deep_learning_amd.ops import kernels as Kk
+    g = torch.Generator().manual_seed(N + C)
+    x = torch.randn((N, C, H, H), generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    P = (H + 2 * pad - R) // stride + 1
+    dy = torch.randn((N, K, P, P), generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    a = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+    b = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+    assert torch.equal(a, b)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (K, C, R, R), dy.float(), stride, pad)
+    assert float((a - ref).abs().max()) < 2e-2 * float(ref.abs().max()) + 1e-3
+    out = torch.ones((K, R, R, C), dtype=torch.float32, device="cuda").permute(0, 3, 1, 2)
+    Kk.conv2d_wgrad(dy, x, R, R, stride, pad, out=out)
+    assert torch.equal(out, a + 1.0) or float((out - (a + 1.0)).abs().max()) < 1e-5 * float(a.abs().max())
+
+
 # ----------------------------------------------------------------------------------------------- fused LSTM layer
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T,I,H", [(40, 64, 32, 128), (16, 7, 64, 64), (33, 12, 128, 128), (5, 20, 32, 64)])
@@ -382,6 +405,48 @@ def test_lstm_layer_matches_fp32_reference(B, T, I, H):
     assert rel(xg.grad, xr.grad) < 3e-2
     for name in ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"):
         assert rel(getattr(ours, name).grad, getattr(ref, name).grad) < 3e-2, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,Kr,N", [(100, 256, 32), (4096 + 37, 512, 128), (31, 512, 64), (128, 256, 64)])
+def test_rows_gemm_nt_matches_fp32(M, Kr, N):
+    """The LSTM input-gradient GEMM (csrc/lstm.hip: rows_gemm_nt_kernel), ragged row counts included."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn((M, Kr), generator=g).to(torch.bfloat16).cuda()
+    bt = (torch.randn((N, Kr), generator=g) / Kr ** 0.5).to(torch.bfloat16).cuda()
+    out = K.rows_gemm_nt(a, bt)
+    ref = a.float() @ bt.float().t()
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    assert float((out.float() - ref).abs().max()) < 1e-2 * float(ref.abs().max()) + 1e-3
+
+
+@pytest.mark.gpu
+def test_lstm_weight_gradients_go_straight_into_the_arena():
+    """With the parameters in a ParamArena the layer reads the arena's bf16 shadow pairs and accumulates both weight
+    gradients in place on the side stream; results equal the private-copy path."""
+    from distributed_deep_learning_amd import nn as dnn
+    from distributed_deep_learning_amd.ops import streams
+    from distributed_deep_learning_amd.parallel import ParamArena
+    torch.manual_seed(4)
+    plain = dnn.LSTM(32, 128).cuda()
+    pooled = dnn.LSTM(32, 128).cuda()
+    pooled.load_state_dict(plain.state_dict())
+    arena = ParamArena(pooled.named_parameters())
+    assert pooled.weight_ih_l0._ddl_shadow_t.shape == (32, 512) and pooled.weight_hh_l0._ddl_shadow_t.shape == (128, 512)
+    x = torch.randn(48, 64, 32, device="cuda")
+    w = torch.randn(48, 64, 128, device="cuda") / 8.0
+    grads = {}
+    for tag, m in (("plain", plain), ("arena", pooled)):
+        xg = x.clone().requires_grad_(True)
+        out, _ = m(xg)
+        (out.float() * w).sum().backward()
+        streams.join()
+        torch.cuda.synchronize()
+        grads[tag] = [xg.grad.float()] + [p.grad.float().clone() for p in m.parameters()]
+    assert arena.grad_is_arena_view(pooled.weight_ih_l0) and arena.grad_is_arena_view(pooled.weight_hh_l0)
+    for a, b in zip(grads["plain"], grads["arena"]):
+        assert float((a - b).norm()) <= 2e-3 * float(a.norm()) + 1e-6
 
 
 @pytest.mark.gpu
