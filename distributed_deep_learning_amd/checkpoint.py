@@ -29,6 +29,12 @@ def _barrier() -> None:
         td.barrier()
 
 
+def _dropout_state() -> Dict[str, Any]:
+    """[seed, counter] of the fused-dropout generators (``ops.kernels.rng_state``); empty when no kernel drew a mask."""
+    from .ops import kernels
+    return kernels.dropout_state_dict()
+
+
 def model_state(model) -> Dict[str, torch.Tensor]:
     return {k: v.detach().to("cpu").contiguous().clone() for k, v in model.state_dict().items()}
 
@@ -45,7 +51,8 @@ def save(path: str, model, optimizer=None, scheduler=None, epoch: int = 0, step:
         "step": int(step),
         "sampler": sampler.state_dict() if sampler is not None and hasattr(sampler, "state_dict") else None,
         "rng": {"torch": torch.get_rng_state(), "python": random.getstate(),
-                "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None},
+                "cuda": torch.cuda.get_rng_state_all() if torch.cuda.is_available() else None,
+                "dropout": _dropout_state()},
         "extra": extra or {},
     }
     r = _rank()
@@ -85,6 +92,9 @@ def load(path: str, model, optimizer=None, scheduler=None, sampler=None, strict:
         random.setstate(payload["rng"]["python"])
         if payload["rng"].get("cuda") is not None and torch.cuda.is_available():
             torch.cuda.set_rng_state_all(payload["rng"]["cuda"])
+    if (payload.get("rng") or {}).get("dropout"):      # always: the fused-dropout mask sequence continues where it stopped
+        from .ops import kernels
+        kernels.load_dropout_state_dict(payload["rng"]["dropout"])          # counters; every rank keeps its own seed
     _barrier()
     return {"epoch": payload["epoch"], "step": payload["step"], "extra": payload.get("extra", {})}
 

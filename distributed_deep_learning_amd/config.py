@@ -54,6 +54,8 @@ class Config:
     global_metrics: bool = False       # all-reduce metrics over ranks (reference reports rank 0's shard)
     graph: Optional[bool] = None       # hipGraph replay of the train step: True / False / None = auto (on for the
                                        # launch-bound workloads: cnn, lstm, mlp, lenet5, resnet18_cifar; 1 process, GPU)
+    deterministic: bool = False        # bit-reproducible weight gradients (slabs + ordered reduce instead of float
+                                       # atomics, csrc/conv_wgrad.hip; 0.6-1.3 % slower on ResNet-50)
     check_replicas: int = 0            # every k steps compare parameter checksums across ranks (debug)
     max_steps: Optional[int] = None    # stop each epoch early (smoke tests)
     inject_fault: Optional[str] = None  # "RANK:STEP": that rank dies (hard exit) before that global step - fault drill
@@ -114,6 +116,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--global-metrics", dest="global_metrics", action="store_true")
     p.add_argument("--graph", nargs="?", const="on", default="auto", choices=["on", "off", "auto"],
                    help="replay the training step as one captured hipGraph (auto: on for the small, launch-bound workloads)")
+    p.add_argument("--deterministic", action="store_true",
+                   help="bit-reproducible weight gradients (ordered reduce of the split-M partial tiles instead of atomics)")
     p.add_argument("--check-replicas", dest="check_replicas", type=int, default=0)
     p.add_argument("--max-steps", dest="max_steps", type=int, default=None)
     p.add_argument("--inject-fault", dest="inject_fault", default=None, metavar="RANK:STEP",

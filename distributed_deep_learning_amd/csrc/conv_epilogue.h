@@ -1,4 +1,4 @@
-// Shared epilogue of the 256 x BN implicit-GEMM convolution kernels (conv_ring.hip, conv_patch.hip):
+// Shared epilogue of the 256 x BN implicit-GEMM convolution kernels (conv_ring.hip):
 // accumulators -> (bias, ReLU) -> bf16 tile in LDS -> full-line global stores (+ addend, + BN partial sums).
 // 512 threads = 8 waves (4 along pixels x 2 along channels), each wave 64 pixels x BN/2 channels.
 // `smem` must offer LDS_BYTES bytes that no wave reads any more (callers __syncthreads() first).

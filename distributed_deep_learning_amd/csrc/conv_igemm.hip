@@ -339,7 +339,6 @@ static int launch_any(ConvParams& p, hipStream_t st) {
     return ddl_launch_conv_big(b, MODE, st);
   }
   if (use_ring && ddl_conv_pring_supported(p)) return ddl_launch_conv_pring(p, MODE, st);
-  if (use_ring && !bwd_sums && ddl_conv_patch_supported(p)) return ddl_launch_conv_patch(p, MODE, st);
   if (use_ring && ddl_conv_ring_supported(p)) return ddl_launch_conv_ring(p, MODE, st);
   if (bwd_sums) return -9;                                     // only the ring kernel's epilogue takes these sums
   p.tiles_m = (p.M + 127) / 128;

@@ -55,7 +55,6 @@ struct ConvParams {
   int out_ld;
   BnFin fin;
   int fin_done;                           // set by a launcher whose kernel performs the fused finalize
-  int dbg;                                // conv_big.hip diagnostics (DDL_BIG_DBG bits; 0 in normal use)
   int mode_hint;                          // 0 fwd, 1 dgrad (set by the launcher before dispatch)                // row -> (n, oh, ow) decode without integer division   // operand sizes (for the buffer descriptors of the LDS-DMA kernel)
 };
 
@@ -67,11 +66,7 @@ int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream);
 bool ddl_conv_pring_supported(const ConvParams& p);
 int ddl_launch_conv_pring(ConvParams& p, int mode, hipStream_t stream);
 
-// conv_big.hip (256 x 256 / 512 x 128 block tiles, two wave groups half a K-step apart, persistent: the MFMA-bound layers)
+// conv_big.hip (256 x 256 block tiles, two wave groups half a K-step apart, persistent: the MFMA-bound layers)
 int ddl_conv_big_shape(const ConvParams& p);
 int ddl_conv_big_split(const ConvParams& p);
 int ddl_launch_conv_big(ConvParams& p, int mode, hipStream_t stream);
-
-// conv_patch.hip (3x3 / stride 1 / pad 1 with an LDS-resident input patch)
-bool ddl_conv_patch_supported(const ConvParams& p);
-int ddl_launch_conv_patch(ConvParams& p, int mode, hipStream_t stream);

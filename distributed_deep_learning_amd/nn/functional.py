@@ -73,11 +73,9 @@ _WGRAD_FIRST = os.environ.get("DDL_WGRAD_FIRST", "1") != "0"
 _WGRAD_FIRST_PLAIN = os.environ.get("DDL_WGRAD_FIRST_PLAIN", "0") != "0"
 # forward: projection-shortcut conv on the side stream, beside the main path's first units (A/B switch)
 _FORK_SHORTCUT = os.environ.get("DDL_FORK_SHORTCUT", "1") != "0"
-# BN-backward sums taken in the producing dgrad's epilogue (skips the reduce pass of the in-block BNs).  Measured on
-# ResNet-50, B=512: 13.41k img/s with it vs 13.49-13.54k without - the extra epilogue work (z + mask reads, LDS
-# reduction, atomics) sits on the critical path of short 1x1 dgrads and costs more than the bandwidth-bound reduce
-# passes it removes.  Kept as an option.
-_DGRAD_BN_SUMS = int(os.environ.get("DDL_DGRAD_BN_SUMS", "0"))       # 1: every in-block dgrad, 2: only 3x3 and larger
+# (BN-backward sums taken in the producing dgrad's epilogue - skipping the reduce pass of the in-block BatchNorms - were
+#  built in round 2 and measured slower on ResNet-50, 13.41k vs 13.49-13.54k img/s at batch 512: docs/STATUS.md.  The
+#  option is gone; the dgrad epilogue's sums hook itself lives on in the conv + bias + ReLU chains of VGG below.)
 
 
 def _bn_bwd_pair(dout, mask, saved, metas, ia, ib):
@@ -239,7 +237,7 @@ class ResidualBlock(torch.autograd.Function):
         grads = {}
 
         def back(idx, dy, need_dx, addend=None, addend_mask=None, relu_mask=None, want_dres=False, addend_step=1,
-                 compact_dx=False, bn_done=None, presummed=False, sums_for=None):
+                 compact_dx=False, bn_done=None):
             """BN(+ReLU) backward -> dgrad (+ addend) -> wgrad of unit ``idx``.  ``relu_mask`` overrides the unit's
             own activation: the unit then sees ``dy * mask`` (used to push the block-output ReLU into the shortcut)."""
             inp, y_conv, mask, vec, crsk = saved[5 * idx:5 * idx + 5]
@@ -252,7 +250,7 @@ class ResidualBlock(torch.autograd.Function):
                 dres = None
             else:
                 dconv, dres, dgamma, dbeta = _bn_bwd(dy, mask, y_conv, bn.weight, bn.bias, bn.weight, rows[0], rows[1],
-                                                     relu, want_dres, slab, presummed)
+                                                     relu, want_dres, slab)
             dx = None
             R, S = conv.kernel_size
             dw = (_wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
@@ -263,7 +261,7 @@ class ResidualBlock(torch.autograd.Function):
                 dx = K.conv2d_dgrad(dconv, crsk, tuple(dconv.shape[2:]), 1, 0)
             elif need_dx:
                 dx = K.conv2d_dgrad(dconv, crsk, tuple(inp.shape[2:]), conv.stride[0], conv.padding[0], addend=addend,
-                                    addend_mask=addend_mask, addend_step=addend_step, bn_sums=sums_for)
+                                    addend_mask=addend_mask, addend_step=addend_step)
             if not _WGRAD_FIRST:
                 dw = _wgrad(conv.weight, dconv, inp, R, S, conv.stride[0], conv.padding[0], conv.in_channels)
             grads[idx] = (dw, dgamma, dbeta)
@@ -282,32 +280,12 @@ class ResidualBlock(torch.autograd.Function):
             if ctx.has_ds and _PAIR_BN:
                 # last main BN and shortcut BN see the same gradient behind the same mask: one pair of passes
                 last_done, ds_done = _bn_bwd_pair(dout, out_mask, saved, metas, last, 0)
-            # inside the block every dgrad output is the gradient of the previous unit's BN+ReLU: its epilogue takes that
-            # BN's backward sums (sum g, sum g*z) while the tile is on chip, and the BN backward skips its reduce pass
-            def sums_of(idx):
-                prev = idx - 1
-                if not _DGRAD_BN_SUMS or prev < first_main:
-                    return None
-                conv = metas[idx][0]
-                if _DGRAD_BN_SUMS == 2 and conv.kernel_size == (1, 1):
-                    return None
-                crsk = saved[5 * idx + 4]
-                if not K.dgrad_bn_sums_ok(saved[5 * idx + 1], crsk, conv.stride[0], *conv.kernel_size):
-                    return None
-                return (saved[5 * prev + 1], saved[5 * prev + 2], metas[prev][4])
-
-            pre = False
-            if last > first_main:
-                sf = sums_of(last)
-                if ds_done is not None:
-                    d, _ = back(last, dout, True, bn_done=last_done, sums_for=sf)
-                else:
-                    d, _ = back(last, dout, True, sums_for=sf)
-                pre = sf is not None
+            if ds_done is not None:
+                d, _ = back(last, dout, True, bn_done=last_done)
+            else:
+                d, _ = back(last, dout, True)
             for idx in range(last - 1, first_main, -1):
-                sf = sums_of(idx)
-                d, _ = back(idx, d, True, presummed=pre, sums_for=sf)
-                pre = sf is not None
+                d, _ = back(idx, d, True)
             if ctx.has_ds:
                 dsc = metas[0][0]
                 step = dsc.stride[0]
@@ -317,10 +295,10 @@ class ResidualBlock(torch.autograd.Function):
                 # (issuing this dgrad early on the side stream, behind an event, was measured: no gain over the forward fork)
                 dshort, _ = back(0, dout, need_x, relu_mask=out_mask, compact_dx=compact, bn_done=ds_done)
                 dx, _ = back(first_main, d, need_x, addend=dshort if need_x else None,
-                             addend_step=step if compact else 1, presummed=pre)
+                             addend_step=step if compact else 1)
             else:
                 dx, _ = back(first_main, d, need_x, addend=dout if need_x else None,
-                             addend_mask=out_mask if need_x else None, presummed=pre)
+                             addend_mask=out_mask if need_x else None)
         else:                                         # degenerate: the only main unit carries the residual
             dx, r = back(first_main, dout, need_x, want_dres=True)
             if ctx.has_ds:

@@ -10,11 +10,10 @@ Conventions
 """
 from __future__ import annotations
 
-import os
-
 import torch
 
 from . import _lib
+from . import state as _state
 from ._lib import check, ptr, stream_ptr
 
 CL = torch.channels_last
@@ -346,52 +345,27 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
 
 
 _WGRAD_PLANS: dict = {}
-# 0 restores the float-atomic meeting of the split-M partial tiles (debug knob, docs/STATUS.md "debug switches")
-_WGRAD_REPRODUCIBLE = os.environ.get("DDL_WGRAD_ATOMICS", "0") != "1"
-
-
-_WGRAD_PENDING: dict = {}        # raw stream -> workspace of the deferred launch whose slabs are still unreduced
 
 
 def _wgrad_workspace(lib, geom, device):
-    """Scratch for the split-M partial tiles of one filter-gradient launch (``csrc/conv_wgrad.hip``: slabs + ordered
-    reduce = bit-reproducible gradients).  Sized by the launcher's own plan, cached per geometry; the buffer comes from
-    the caching allocator on the CURRENT stream, so consecutive launches reuse blocks in stream order.
-
-    Inside the wgrad side-stream fork (``ops.streams``) the launch is DEFERRED: its slabs are reduced by the next filter
-    gradient on that stream (no separate launch between two of them) or by :func:`wgrad_flush`, which the join and the
-    reducer's bucket launch call; the workspace is kept alive here until then.
-    Returns ``(tensor or None, elements, defer flag, raw stream)``."""
-    st = stream_ptr()
-    if not _WGRAD_REPRODUCIBLE:
-        return None, 0, 0, st
+    """Scratch for the split-M partial tiles of one filter-gradient launch in REPRODUCIBLE mode (``ops.state``:
+    ``set_deterministic`` / ``DDL_DETERMINISTIC=1`` / ``torch.use_deterministic_algorithms``): ``csrc/conv_wgrad.hip``
+    then stores the partial tiles as slabs and adds them in a fixed order instead of meeting in float atomics, which
+    makes every filter / Linear / LSTM weight gradient reproducible to the bit.  Sized by the launcher's own plan,
+    cached per geometry; the buffer comes from the caching allocator on the CURRENT stream (the wgrad side stream), so
+    consecutive launches reuse one block in stream order.  Returns ``(tensor or None, elements)``; ``(None, 0)`` selects
+    the atomics (default: 0.6-1.3 % faster per ResNet-50 step, the slabs' extra bytes in an HBM-bound step)."""
+    if not _state.deterministic():
+        return None, 0
     need = _WGRAD_PLANS.get(geom)
     if need is None:
         need = int(lib.ddl_conv_wgrad_plan(*geom))
         if need < 0:
             raise ValueError(f"conv wgrad: unsupported problem {geom} (rc {need})")
         _WGRAD_PLANS[geom] = need
-    from . import streams
-    defer = int(streams.in_fork(device, st))
-    ws = torch.empty(need, dtype=torch.float32, device=device) if need > 0 else None
-    return ws, need, defer, st
-
-
-def _wgrad_launched(st, ws, defer) -> None:
-    """After a filter-gradient launch on raw stream ``st``: the launch has reduced whatever was pending there; its own
-    slabs are pending now when it was deferred."""
-    if defer and ws is not None:
-        _WGRAD_PENDING[st] = ws
-    else:
-        _WGRAD_PENDING.pop(st, None)
-
-
-def wgrad_flush() -> None:
-    """Reduce the slabs a deferred filter gradient left on the CURRENT stream (no-op without one)."""
-    st = stream_ptr()
-    if st in _WGRAD_PENDING:
-        check(_lib.require().ddl_conv_wgrad_flush(st), "conv_wgrad_flush")
-        del _WGRAD_PENDING[st]
+    if need == 0:
+        return None, 0
+    return torch.empty(need, dtype=torch.float32, device=device), need
 
 
 def conv2d_wgrad(dy, x, R, S, stride=1, pad=0, out=None):
@@ -405,19 +379,17 @@ def conv2d_wgrad(dy, x, R, S, stride=1, pad=0, out=None):
     N2, Cc, H, W = x.shape
     if N2 != N or conv_out_size(H, R, stride, pad) != P or conv_out_size(W, S, stride, pad) != Q:
         raise ValueError("conv2d_wgrad: geometry mismatch")
-    ws, ws_n, defer, st = _wgrad_workspace(lib, (N, H, W, Cc, K, P, Q, R, S, stride, pad), x.device)
+    ws, ws_n = _wgrad_workspace(lib, (N, H, W, Cc, K, P, Q, R, S, stride, pad), x.device)
     if out is not None:
         if (out.dtype != torch.float32 or tuple(out.shape) != (K, Cc, R, S)
                 or not out.permute(0, 2, 3, 1).is_contiguous()):
             raise ValueError("conv2d_wgrad: out must be fp32 [K,C,R,S] with channels-last (KRSC) strides")
         check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(out), N, H, W, Cc, K, P, Q, R, S, stride, pad, ptr(ws), ws_n,
-                                 defer, st), "conv2d_wgrad")
-        _wgrad_launched(st, ws, defer)
+                                 stream_ptr()), "conv2d_wgrad")
         return out
     dw = torch.zeros((K, R, S, Cc), dtype=torch.float32, device=x.device)
     check(lib.ddl_conv_wgrad(ptr(dy), ptr(x), ptr(dw), N, H, W, Cc, K, P, Q, R, S, stride, pad, ptr(ws), ws_n,
-                             0, st), "conv2d_wgrad")
-    _wgrad_launched(st, ws, 0)
+                             stream_ptr()), "conv2d_wgrad")
     return dw.permute(0, 3, 1, 2)
 
 
@@ -858,10 +830,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor
         raise ValueError("gemm_tn: operands must be contiguous [M, Ka] / [M, Cb] with Ka, Cb multiples of 8")
     if out.dtype != torch.float32 or tuple(out.shape) != (Ka, Cb) or not out.is_contiguous():
         raise ValueError("gemm_tn: out must be a contiguous fp32 [Ka, Cb] tensor")
-    ws, ws_n, defer, st = _wgrad_workspace(lib, (M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0), a.device)
-    check(lib.ddl_conv_wgrad(ptr(a), ptr(b), ptr(out), M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0, ptr(ws), ws_n, defer, st),
+    ws, ws_n = _wgrad_workspace(lib, (M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0), a.device)
+    check(lib.ddl_conv_wgrad(ptr(a), ptr(b), ptr(out), M, 1, 1, Cb, Ka, 1, 1, 1, 1, 1, 0, ptr(ws), ws_n, stream_ptr()),
           "gemm_tn")
-    _wgrad_launched(st, ws, defer)
     return out
 
 
@@ -882,14 +853,53 @@ def transpose_pad(x: torch.Tensor, rows_padded: int | None = None) -> torch.Tens
 _RNG_STATE: dict = {}
 
 
+_RNG_STREAM = 0          # which independent stream of masks this process draws (its data-parallel rank)
+
+
+def _rng_seed() -> int:
+    # splitmix-style mix of (torch seed, stream): ranks that share torch.manual_seed(s) still draw different masks
+    z = (torch.initial_seed() + 0x9E3779B97F4A7C15 * (_RNG_STREAM + 1)) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return (z ^ (z >> 31)) & 0x7FFFFFFFFFFFFFFF
+
+
 def rng_state(device) -> torch.Tensor:
-    """Device-resident ``[seed, counter]`` of the dropout generator (seeded from ``torch.initial_seed()`` on first use;
-    the kernels advance the counter themselves, so captured graphs draw fresh masks on every replay)."""
+    """Device-resident ``[seed, counter]`` of the dropout generator (seeded from ``torch.initial_seed()`` and the
+    process's mask stream - :func:`seed_dropout` - on first use; the kernels advance the counter themselves, so captured
+    graphs draw fresh masks on every replay)."""
     key = (device.type, device.index)
     st = _RNG_STATE.get(key)
     if st is None:
-        st = _RNG_STATE[key] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=device)
+        st = _RNG_STATE[key] = torch.tensor([_rng_seed(), 0], dtype=torch.int64, device=device)
     return st
+
+
+def seed_dropout(stream: int = 0) -> None:
+    """(Re)seed the dropout generators of this process from ``torch.initial_seed()`` and ``stream`` (the data-parallel
+    rank: replicas seeded alike by ``torch.manual_seed`` must not drop the same units of their different samples).
+    Existing device states are rewritten IN PLACE (captured graphs hold their address); counters restart at 0."""
+    global _RNG_STREAM
+    _RNG_STREAM = int(stream)
+    for st in _RNG_STATE.values():
+        st.copy_(torch.tensor([_rng_seed(), 0], dtype=torch.int64))
+
+
+def dropout_state_dict() -> dict:
+    """``{"cuda:0": [seed, counter], ...}`` for checkpoints (plain ints)."""
+    return {(k[0] if k[1] is None else f"{k[0]}:{k[1]}"): [int(v) for v in st.cpu().tolist()] for k, st in _RNG_STATE.items()}
+
+
+def load_dropout_state_dict(sd: dict, counters_only: bool = True) -> None:
+    """Restore the mask COUNTERS (and the seeds too with ``counters_only=False``): a resumed run continues the mask
+    sequence where the checkpointed one stopped; the seed stays the one this rank was given."""
+    for name, (seed, counter) in (sd or {}).items():
+        dev = torch.device(name)
+        if dev.type == "cuda" and (not torch.cuda.is_available() or dev.index >= torch.cuda.device_count()):
+            continue
+        st = rng_state(dev)
+        cur = st.cpu().tolist()
+        st.copy_(torch.tensor([cur[0] if counters_only else int(seed), int(counter)], dtype=torch.int64))
 
 
 _ACCUMULATORS: dict = {}

@@ -112,6 +112,11 @@ class Trainer:
                    master_port=None if external else cfg.master_port, comm=cfg.comm,
                    bind_device=cfg.mode not in ("model", "pipeline"))
         torch.manual_seed(cfg.seed)                           # reference: torch.manual_seed(42), main.py:132
+        from .ops import kernels as _kernels
+        from .ops import state as _ops_state
+        _kernels.seed_dropout(info.rank)                      # same weights everywhere, but every replica its own masks
+        if cfg.deterministic:
+            _ops_state.set_deterministic(True)
 
         model = models.build(cfg.model, **_model_kwargs(cfg))
         if cfg.mode == "pipeline":

@@ -316,63 +316,36 @@ def test_bn_relu_maxpool_fused_unit(shape, pool, pooled_sums):
     assert (err > 3e-2 + 3e-2 * xr.grad.abs()).float().mean().item() < 0.01, err.max().item()
 
 
-def test_conv_patch_kernel_opt_in_subprocess():
-    """The opt-in LDS-resident-patch 3x3 kernel (DDL_CONV_PATCH=1 is read once per process) against the default path."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import sys, torch
-sys.path.insert(0, %r)
-import torch.nn.functional as F
-from distributed_deep_learning_amd.ops import kernels as K
-CL = torch.channels_last
-dev = torch.device("cuda:0")
-for (N, C, H, W, Kc) in [(2, 64, 56, 56, 64), (3, 256, 14, 14, 256), (1, 32, 20, 36, 96)]:
-    g = torch.Generator().manual_seed(1)
-    x = torch.randn((N, C, H, W), generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
-    w = (torch.randn((Kc, C, 3, 3), generator=g) / (C * 9) ** 0.5).to(dev).contiguous(memory_format=CL)
-    wk, wt = K.filter_repack(w)
-    wq = wk.permute(0, 3, 1, 2).float()
-    y, st = K.conv2d_fwd(x, wk, 1, 1, want_stats=True)
-    ref = F.conv2d(x.float(), wq, None, 1, 1)
-    assert (y.float() - ref).abs().max().item() < 2e-2 + 2e-2 * ref.abs().max().item()
-    s = K.slab_sums(st)
-    assert torch.allclose(s[0], y.float().sum((0, 2, 3)), rtol=1e-3, atol=1e-1)
-    dy = torch.randn(y.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
-    add = torch.randn(x.shape, generator=g).to(torch.bfloat16).to(dev).contiguous(memory_format=CL)
-    dx = K.conv2d_dgrad(dy, wt, (H, W), 1, 1, addend=add)
-    dref = torch.nn.grad.conv2d_input((N, C, H, W), wq, dy.float(), 1, 1) + add.float()
-    assert (dx.float() - dref).abs().max().item() < 3e-2 + 2e-2 * dref.abs().max().item()
-print("PATCH_OK")
-''' % root
-    env = dict(os.environ, DDL_CONV_PATCH="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=110)
-    assert r.returncode == 0 and "PATCH_OK" in r.stdout, r.stdout[-500:] + r.stderr[-1500:]
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,C,H,K,R,stride,pad", [(32, 64, 56, 64, 3, 1, 1), (16, 16, 115, 64, 4, 1, 0), (24, 512, 7, 512, 3, 1, 1),
                                                   (32, 256, 14, 1024, 1, 1, 0), (20, 128, 28, 128, 3, 2, 1)])
 def test_wgrad_is_bit_reproducible_and_accumulates(N, C, H, K, R, stride, pad):
-    """The split-M partial tiles of a filter gradient meet in slabs + an ordered reduce (csrc/conv_wgrad.hip), not in
+    """Deterministic mode (``ops.state.set_deterministic`` / ``--deterministic`` / ``torch.use_deterministic_algorithms``):
+    the split-M partial tiles of a filter gradient meet in slabs + an ordered reduce (csrc/conv_wgrad.hip), not in
     float atomics: two launches on the same operands agree to the BIT, for every tile family (64-channel 3x3 with
     hundreds of splits, the folded stem tile, wide late-layer tiles, plain 1x1, strided), and ``out=`` is accumulated
-    into."""
+    into.  The default (atomics) gives the same numbers up to summation order."""
     from distributed_deep_learning_amd.ops import kernels as Kk
+    from distributed_deep_learning_amd.ops import state
     g = torch.Generator().manual_seed(N + C)
     x = torch.randn((N, C, H, H), generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
     P = (H + 2 * pad - R) // stride + 1
     dy = torch.randn((N, K, P, P), generator=g).to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
-    a = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
-    b = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+    fast = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+    state.set_deterministic(True)
+    try:
+        assert state.deterministic()
+        a = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+        b = Kk.conv2d_wgrad(dy, x, R, R, stride, pad)
+        out = torch.ones((K, R, R, C), dtype=torch.float32, device="cuda").permute(0, 3, 1, 2)
+        Kk.conv2d_wgrad(dy, x, R, R, stride, pad, out=out)
+    finally:
+        state.set_deterministic(False)
     assert torch.equal(a, b)
     ref = torch.nn.grad.conv2d_weight(x.float(), (K, C, R, R), dy.float(), stride, pad)
     assert float((a - ref).abs().max()) < 2e-2 * float(ref.abs().max()) + 1e-3
-    out = torch.ones((K, R, R, C), dtype=torch.float32, device="cuda").permute(0, 3, 1, 2)
-    Kk.conv2d_wgrad(dy, x, R, R, stride, pad, out=out)
-    assert torch.equal(out, a + 1.0) or float((out - (a + 1.0)).abs().max()) < 1e-5 * float(a.abs().max())
+    assert float((out - (a + 1.0)).abs().max()) < 1e-5 * float(a.abs().max()) + 1e-6
+    assert float((fast - a).abs().max()) < 1e-4 * float(a.abs().max()) + 1e-5
 
 
 # ----------------------------------------------------------------------------------------------- fused LSTM layer
