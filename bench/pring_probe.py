@@ -108,8 +108,8 @@ def main():
         return
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
     rows = []
-    settings = [("ring", {"DDL_CONV_PRING": "0"}), ("pring", {"DDL_CONV_PRING": "2", "DDL_PRING_MIN_TILES": "512"}),
-                ("ring", {"DDL_CONV_PRING": "0"}), ("pring", {"DDL_CONV_PRING": "2", "DDL_PRING_MIN_TILES": "512"})]
+    settings = [("ring", {"DDL_CONV_PRING": "0"}), ("pring", {"DDL_CONV_PRING": "2"}),
+                ("ring", {"DDL_CONV_PRING": "0"}), ("pring", {"DDL_CONV_PRING": "2"})]
     for name, e in settings:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), str(B), "child"], env=dict(os.environ, **e),
                            capture_output=True, text=True, timeout=280)

@@ -29,6 +29,9 @@ class Config:
     nworkers: int = 0                  # -w  loader threads assembling pinned host batches ahead (file-backed data)
     mode: str = "sequential"           # -m  sequential | model | pipeline | data
     pipeline: int = 2                  # -p  micro-batch size
+    pipeline_schedule: str = "1f1b"    # training schedule of -m pipeline: "1f1b" (a micro-batch's backward is issued as
+                                       # soon as it leaves the last stage) | "gpipe" (the reference: all forwards, then
+                                       # one backward over everything)
     run: int = 1                       # -r  local ranks to spawn for -m data
     # --- made explicit ---
     stages: int = 2                    # devices for model / pipeline mode
@@ -71,6 +74,8 @@ class Config:
             raise ValueError(f"sync must be one of {SYNC_MODES}")
         if self.optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer must be one of {OPTIMIZERS}")
+        if self.pipeline_schedule not in ("1f1b", "gpipe"):
+            raise ValueError("pipeline_schedule must be 1f1b or gpipe")
         if self.batch < 1 or self.epochs < 0 or self.run < 1 or self.pipeline < 1 or self.stages < 1:
             raise ValueError("batch, run, pipeline and stages must be >= 1")
         return self
@@ -93,6 +98,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("-m", "--mode", choices=list(MODES), nargs="?", default="sequential")
     p.add_argument("-p", "--pipeline", type=int, nargs="?", default=2)
     p.add_argument("-r", "--run", type=int, nargs="?", default=1)
+    p.add_argument("--pipeline-schedule", dest="pipeline_schedule", choices=["1f1b", "gpipe"], default="1f1b")
     p.add_argument("--stages", type=int, default=2)
     p.add_argument("--lr", type=float, default=0.01)
     p.add_argument("--momentum", type=float, default=0.9)

@@ -47,7 +47,7 @@ static inline RowMap make_rowmap(int M, int C) {
 }
 
 static inline int apply_grid_cap() {
-  static const int v = [] { const char* e = getenv("DDL_BN_APPLY_GRID"); return e ? atoi(e) : 1024; }();   // 512..8192 within 0.6 %
+  constexpr int v = 1024;   // 512..8192 within 0.6 %
   return v;
 }
 
@@ -504,7 +504,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
                                                             const bf16_t* __restrict__ x, const float* __restrict__ mean,
                                                             const float* __restrict__ invstd, float* __restrict__ slab,
                                                             RowMap rm, BwdFin fin, PoolMap pm = PoolMap()) {
-  __shared__ float red[256 * 16];
+  // 17-float pitch per thread: with 16 every lane of a wave stored to bank 0 or 16 (PMC round 2: 60 % of this kernel's LDS
+  // cycles were bank conflicts - harmless next to its HBM time, since it happens once per block, but free to avoid)
+  __shared__ float red[256 * 17];
   const int tid = threadIdx.x;
   const int col = tid % rm.cpb, rg = tid / rm.cpb;
   const int chunk = blockIdx.y * rm.cpb + col;
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) { red[tid * 16 + q] = s1[q]; red[tid * 16 + 8 + q] = s2[q]; }
+  for (int q = 0; q < 8; ++q) { red[tid * 17 + q] = s1[q]; red[tid * 17 + 8 + q] = s2[q]; }
   __syncthreads();
   const int nout = rm.cpb * 16;
   for (int o = tid; o < nout; o += 256) {
@@ -545,7 +547,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const bf16_t* __rest
     const int ch = blockIdx.y * rm.cpb + c;
     if (ch >= rm.c8) continue;
     float s = 0.f;
-    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 16 + e];
+    for (int g = 0; g < rm.rp; ++g) s += red[(g * rm.cpb + c) * 17 + e];
     const int which = e >> 3, q = e & 7;
     const int slot = FUSE ? (int)(blockIdx.x % (unsigned)fin.nslots) : (int)(blockIdx.x % BN_SLOTS);
     slab_add(slab, ((size_t)slot * 2 + which) * rm.C + (size_t)ch * 8 + q, (double)s);

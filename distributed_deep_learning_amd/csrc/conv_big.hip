@@ -427,7 +427,7 @@ int launch_big_t(ConvParams& p, hipStream_t stream) {
 // uniform taps (IC % 64 == 0; forward at any stride, dgrad at stride 1 with unit output step), at most 32 taps, OC a
 // multiple of 8 above 128, 32-bit byte offsets everywhere.
 static bool big_can_run(const ConvParams& p) {
-  if (p.OC <= 128 || p.bias != nullptr || p.relu || p.in_scale != nullptr || p.fin.counter != nullptr) return false;
+  if (p.OC <= 128 || p.bias != nullptr || p.relu || p.fin.counter != nullptr) return false;
   if (p.bnz != nullptr || p.bnz_mask != nullptr) return false;
   if (p.mode_hint == 0 && p.addend != nullptr) return false;
   if (p.mode_hint == 1 && (p.stats != nullptr || p.o_step != 1 || p.stride != 1)) return false;

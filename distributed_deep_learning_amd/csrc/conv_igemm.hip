@@ -313,10 +313,6 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   p.mode_hint = MODE;
   p.trace = g_conv_trace;
   const bool bwd_sums = MODE == 1 && p.stats != nullptr;
-  if (p.in_scale != nullptr) {                                 // fused producer-BN input: ring kernel only
-    if (!ddl_conv_ring_supported(p)) return -11;
-    return ddl_launch_conv_ring(p, MODE, st);
-  }
   if (use_ring && ddl_conv_big_shape(p) != 0) {
     const int n0 = ddl_conv_big_split(p);
     if (n0 >= p.N) return ddl_launch_conv_big(p, MODE, st);
@@ -358,7 +354,7 @@ extern "C" int ddl_bn_finalize(float* slab, int nslots, int C, float count, cons
 static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out, const float* bias, float* stats,
                            const void* addend, const void* addend_mask, int addend_step, const void* bnz,
                            const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R, int S, int stride,
-                           int pad, int relu, void* stream, const float* in_scale, const float* in_shift, int out_ld = 0,
+                           int pad, int relu, void* stream, int out_ld = 0,
                            const BnFin* fin = nullptr) {
   if (IC % 8 != 0 || OC % 8 != 0) return -1;
   if (out_ld != 0 && (mode != 0 || out_ld < OC || out_ld % 8 != 0 || ((uintptr_t)out & 15) != 0)) return -12;
@@ -378,8 +374,6 @@ static int conv_igemm_impl(int mode, const void* in, const void* wmat, void* out
   if (mode == 1 && ((stats != nullptr) != (bnz != nullptr) || (bnz_mask != nullptr && bnz == nullptr))) return -10;
   if (bn_flags < 0 || bn_flags > 3 || (bn_flags != 0 && (bnz == nullptr || bnz_mask != nullptr))) return -10;
   p.bnz = (const bf16_t*)bnz; p.bnz_mask = (const unsigned char*)bnz_mask; p.bn_flags = bn_flags;
-  if ((in_scale != nullptr) != (in_shift != nullptr) || (in_scale != nullptr && mode != 0)) return -11;
-  p.in_scale = in_scale; p.in_shift = in_shift;
   p.out_ld = out_ld != 0 ? out_ld : OC;
   p.fin = BnFin{};
   p.fin_done = 0;
@@ -451,16 +445,7 @@ extern "C" int ddl_conv_igemm(int mode, const void* in, const void* wmat, void* 
                               const void* bnz_mask, int bn_flags, int N, int OH, int OW, int IH, int IW, int IC, int OC, int R,
                               int S, int stride, int pad, int relu, void* stream) {
   return conv_igemm_impl(mode, in, wmat, out, bias, stats, addend, addend_mask, addend_step, bnz, bnz_mask, bn_flags, N, OH,
-                         OW, IH, IW, IC, OC, R, S, stride, pad, relu, stream, nullptr, nullptr);
-}
-
-// Forward 1x1 / stride-1 convolution whose INPUT is a raw conv output: relu(in * in_scale[c] + in_shift[c]) is formed on
-// the fragments inside the kernel (the producer's BatchNorm + ReLU), statistics of the output go to `stats`.
-extern "C" int ddl_conv_fwd_inbn(const void* in, const void* wmat, void* out, float* stats, const float* in_scale,
-                                 const float* in_shift, int N, int H, int W, int IC, int OC, void* stream) {
-  if (in_scale == nullptr || in_shift == nullptr || stats == nullptr || IC > 512) return -11;
-  return conv_igemm_impl(0, in, wmat, out, nullptr, stats, nullptr, nullptr, 1, nullptr, nullptr, 0, N, H, W, H, W, IC, OC, 1,
-                         1, 1, 0, 0, stream, in_scale, in_shift);
+                         OW, IH, IW, IC, OC, R, S, stride, pad, relu, stream);
 }
 
 // Forward convolution writing its [pixels][OC] result into a channel window of a wider [pixels][out_ld] buffer
@@ -468,7 +453,7 @@ extern "C" int ddl_conv_fwd_inbn(const void* in, const void* wmat, void* out, fl
 extern "C" int ddl_conv_fwd_ld(const void* in, const void* wmat, void* out, int out_ld, float* stats, int N, int OH, int OW,
                                int IH, int IW, int IC, int OC, int R, int S, int stride, int pad, void* stream) {
   return conv_igemm_impl(0, in, wmat, out, nullptr, stats, nullptr, nullptr, 1, nullptr, nullptr, 0, N, OH, OW, IH, IW, IC, OC,
-                         R, S, stride, pad, 0, stream, nullptr, nullptr, out_ld);
+                         R, S, stride, pad, 0, stream, out_ld);
 }
 
 // Forward convolution + BatchNorm statistics + BatchNorm finalize as ONE launch where the kernel supports it: the last
@@ -483,5 +468,5 @@ extern "C" int ddl_conv_fwd_bn(const void* in, const void* wmat, void* out, int 
   fin.gamma = gamma; fin.beta = beta; fin.running_mean = running_mean; fin.running_var = running_var;
   fin.momentum = momentum; fin.eps = eps; fin.vec = vec;
   return conv_igemm_impl(0, in, wmat, out, nullptr, slab, nullptr, nullptr, 1, nullptr, nullptr, 0, N, OH, OW, IH, IW, IC, OC,
-                         R, S, stride, pad, 0, stream, nullptr, nullptr, out_ld, &fin);
+                         R, S, stride, pad, 0, stream, out_ld, &fin);
 }

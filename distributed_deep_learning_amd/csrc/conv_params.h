@@ -44,11 +44,6 @@ struct ConvParams {
   // bn_flags bit 0: no mask tensor, the gate is (bnz > 0) (dx is the gradient of a ReLU OUTPUT bnz: conv+bias+ReLU
   // chains); bit 1: store the gated gradient (the consumer then needs no ReLU-backward pass; sum(g) = its bias grad)
   int bn_flags;
-  // forward only, 1x1 / stride 1 (EPI bit 8): the INPUT is a raw conv output z and the operand the MFMAs see is
-  // relu(z * in_scale[c] + in_shift[c]) — the producer's BatchNorm(+ReLU) applied on the fragment after the LDS read, so
-  // the normalised activation is never written or re-read (fp32 [IC] each, IC <= 512).
-  const float* in_scale;
-  const float* in_shift;
   // forward only: row pitch of `out` in elements (>= OC, multiple of 8).  The tile is written into a channel window of
   // a wider [pixels][out_ld] buffer (`out` already points at the window's first channel): a dense block's feature map
   // grows in place, no concatenation copy.

@@ -368,7 +368,7 @@ int launch_pring(ConvParams& p, hipStream_t stream) {
 bool ddl_conv_pring_supported(const ConvParams& p) {
   static const int enabled = [] { const char* e = getenv("DDL_CONV_PRING"); return e ? atoi(e) : 1; }();
   if (!enabled) return false;
-  if (p.OC <= 64 || p.bias != nullptr || p.relu || p.in_scale != nullptr || p.fin.counter != nullptr) return false;
+  if (p.OC <= 64 || p.bias != nullptr || p.relu || p.fin.counter != nullptr) return false;
   if (p.bnz != nullptr || p.bnz_mask != nullptr || p.trace != nullptr) return false;
   if (p.mode_hint == 0 && p.addend != nullptr) return false;
   if (p.mode_hint == 1 && (p.stats != nullptr || p.o_step != 1 || p.stride != 1)) return false;
@@ -376,7 +376,7 @@ bool ddl_conv_pring_supported(const ConvParams& p) {
   if (p.addend == nullptr && p.addend_mask != nullptr) return false;
   if (p.out_ld != p.OC && p.mode_hint != 0) return false;
   const long long tiles = (long long)((p.M + PBM - 1) / PBM) * ((p.OC + PBN - 1) / PBN);
-  static const int min_tiles = [] { const char* e = getenv("DDL_PRING_MIN_TILES"); return e ? atoi(e) : 1024; }();
+  constexpr int min_tiles = 1024;
   if (tiles < min_tiles || tiles < 512 || tiles >= (1ll << 30)) return false;
   const int ksteps = (p.Kred + PBK - 1) / PBK;
   if (ksteps < 2 || p.IC < PBK) return false;

@@ -45,15 +45,16 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
-// BK = 32 stages are sized for TWO blocks per CU (4 waves per SIMD = 128 VGPRs); every variant fits on its own except
-// the input-BatchNorm one (EPI & 8), which is held to that budget explicitly.
+// BK = 32 stages are sized for TWO blocks per CU (4 waves per SIMD = 128 VGPRs); every variant fits on its own.
+// (Round 2 had a variant that applied the PRODUCER's BatchNorm + ReLU to the input fragments after the LDS read, so the
+//  normalised activation was never written: 0.92 x at 56x56, 1.05-1.2 x elsewhere - the transform competes with the MFMA
+//  issue slots - and the filter gradient still needs the normalised tensor.  Measured, rejected, removed: docs/STATUS.md.)
 // UNI: every K-step lies inside ONE filter tap for all lanes (IC % BK == 0; forward, or dgrad at stride 1).  The tap
 // cursor then lives in scalar registers, each pixel row carries a precomputed byte offset and a bit mask of its in-bounds
 // taps, and a stage's address work shrinks from ~40 vector instructions (six quarter-rate integer multiplies among
 // them, all in front of the MFMA block) to an add, a bit test and a select per LDS-DMA.
 template <int BN, int BK, int MODE, int EPI, bool UNI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(((EPI & 8) != 0 && BK == 32) ? 4 : 1)))
-void conv_ring_kernel(const ConvParams p) {
+__global__ __launch_bounds__(512) void conv_ring_kernel(const ConvParams p) {
   constexpr int RP = BK * 2;                // LDS row pitch in bytes
   constexpr int CH = BK / 8;                // 16-byte chunks per row
   constexpr int RW = 1024 / RP;             // rows per LDS-DMA wave-instruction
@@ -211,18 +212,6 @@ void conv_ring_kernel(const ConvParams p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // EPI & 8: per-input-channel scale / shift of the producer's BatchNorm, staged behind the ring ([2][IC] floats;
-  // channels past IC read as scale 0 / shift 0, i.e. relu(0) = 0, matching the zero-filled weight columns)
-  float* const aff = reinterpret_cast<float*>(smem + RNS * STAGE);
-  const int icp = (p.IC + BK - 1) / BK * BK;
-  if constexpr ((EPI & 8) != 0) {
-    for (int c = tid; c < icp; c += 512) {
-      aff[c] = c < p.IC ? p.in_scale[c] : 0.f;
-      aff[icp + c] = c < p.IC ? p.in_shift[c] : 0.f;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the raw s_barrier of the K loop does not wait for LDS stores
-  }
-
   const int ksteps = (p.Kred + BK - 1) / BK;
 
   issue(0);
@@ -264,29 +253,6 @@ void conv_ring_kernel(const ConvParams p) {
       // refill the stage tile t-1 just vacated — AFTER this step's fragment reads are in flight, so the address
       // arithmetic of the refill overlaps the LDS latency instead of delaying the first MFMA behind the barrier
       if (ks == 0 && t + 2 < ksteps) issue(stage == 0 ? 2 : stage - 1);
-      if constexpr ((EPI & 8) != 0) {
-        // 1x1 conv: reduction index == input channel.  This lane's 8 fragment elements are channels cb .. cb+7.
-        const int cb = t * BK + ch * 8;
-        // two passes of 4 channels each: 8 coefficient registers live instead of 16 (the variant must stay under the
-        // 128 VGPRs that keep two blocks on a CU at BK = 32)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const f32x4 sv = *reinterpret_cast<const f32x4*>(aff + cb + 4 * h);
-          const f32x4 hv = *reinterpret_cast<const f32x4*>(aff + icp + cb + 4 * h);
-#pragma unroll
-          for (int j = 0; j < TM; ++j) {
-            u32x4 raw = __builtin_bit_cast(u32x4, b[j]);
-            const unsigned lo = raw[2 * h], hi = raw[2 * h + 1];
-            const float f0 = fmaxf(__uint_as_float(lo << 16) * sv[0] + hv[0], 0.f);
-            const float f1 = fmaxf(__uint_as_float(lo & 0xffff0000u) * sv[1] + hv[1], 0.f);
-            const float f2 = fmaxf(__uint_as_float(hi << 16) * sv[2] + hv[2], 0.f);
-            const float f3 = fmaxf(__uint_as_float(hi & 0xffff0000u) * sv[3] + hv[3], 0.f);
-            raw[2 * h] = pack_bf16x2(f0, f1);
-            raw[2 * h + 1] = pack_bf16x2(f2, f3);
-            b[j] = __builtin_bit_cast(bf16x8, raw);
-          }
-        }
-      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -307,8 +273,7 @@ void conv_ring_kernel(const ConvParams p) {
 
 template <int BN, int BK, int MODE, int EPI, bool UNI>
 int launch_ring_u(ConvParams& p, hipStream_t stream) {
-  // EPI & 8: room for the [2][IC <= 512, padded to BK] fp32 affine vectors behind the ring (still two blocks per CU at BK=32)
-  constexpr int smem = RNS * (RBM + BN) * BK * 2 + ((EPI & 8) ? 2 * 512 * 4 : 0);
+  constexpr int smem = RNS * (RBM + BN) * BK * 2;
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_ring_kernel<BN, BK, MODE, EPI, UNI>), smem);
   if (rc != 0) return rc;
@@ -320,25 +285,18 @@ int launch_ring_u(ConvParams& p, hipStream_t stream) {
 }
 
 // Uniform-tap fast path whenever a K-step never straddles two taps (and never runs past the reduction): IC % BK == 0,
-// forward or stride-1 dgrad, at most 32 taps for the per-row mask.  The input-BatchNorm experiment (EPI & 8) keeps the
-// generic path.  DDL_RING_UNI=0 switches it off (A/B).
+// forward or stride-1 dgrad, at most 32 taps for the per-row mask.  DDL_RING_UNI=0 switches it off (A/B).
 template <int BN, int BK, int MODE, int EPI>
 int launch_ring(ConvParams& p, hipStream_t stream) {
   static const int uni_on = [] { const char* e = getenv("DDL_RING_UNI"); return e ? atoi(e) : 1; }();
-  if constexpr ((EPI & 8) == 0) {
-    if (uni_on && p.IC % BK == 0 && (MODE == 0 || p.stride == 1) && p.nR * p.nS <= 32)
-      return launch_ring_u<BN, BK, MODE, EPI, true>(p, stream);
-  }
+  if (uni_on && p.IC % BK == 0 && (MODE == 0 || p.stride == 1) && p.nR * p.nS <= 32)
+    return launch_ring_u<BN, BK, MODE, EPI, true>(p, stream);
   return launch_ring_u<BN, BK, MODE, EPI, false>(p, stream);
 }
 
 template <int BN, int BK>
 int dispatch_ring(ConvParams& p, int mode, hipStream_t stream) {
   if (mode == 0) {
-    if (p.in_scale != nullptr) {                                 // producer BN(+ReLU) applied to the input fragments
-      if (p.stats == nullptr || p.bias != nullptr || p.relu) return -11;
-      return launch_ring<BN, BK, 0, 10>(p, stream);
-    }
     if (p.stats != nullptr) {
       if (p.bias != nullptr || p.relu) return -6;               // statistics are taken of the raw conv output
       if (p.fin.counter != nullptr) {                            // + BatchNorm finalize by the last block of each tile column
@@ -370,8 +328,6 @@ int ring_bk(const ConvParams& p) {
 
 // 32-bit byte offsets inside both operands, and room for the out-of-range sentinel above them.
 bool ddl_conv_ring_supported(const ConvParams& p) {
-  if (p.in_scale != nullptr && !(p.mode_hint == 0 && p.R == 1 && p.S == 1 && p.stride == 1 && p.pad == 0 && p.IC <= 512))
-    return false;
   if (p.mode_hint == 1 && (p.bias != nullptr || p.relu || (p.stats != nullptr && p.bnz == nullptr))) return false;
   if (p.mode_hint == 0 && p.addend != nullptr) return false;
   if (p.stats != nullptr && (p.bias != nullptr || p.relu)) return false;

@@ -633,7 +633,7 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   // ResNet-50 (bench/conv_layers.py w): the ring is ~15 % faster at batch 512 once its DMA issue is hidden from
   // hipcc's waitcnt insertion (see wg_lds_dma16).
   static const int use_ring = [] { const char* e = getenv("DDL_WGRAD_RING"); return e ? atoi(e) : 1; }();
-  static const int groups = [] { const char* e = getenv("DDL_WGRAD_GROUPS"); return e ? atoi(e) : 2; }();
+  constexpr int groups = 2;
   const bool ring = use_ring && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull;
   // Measured per layer (bench/conv_layers.py, B=256): pairing the groups pays where the atomic tail dominates, i.e. the
   // plain 1x1 convs with a short reduction per tile (-8..-20 %); 3x3 and the big first-in-stage 1x1 layers lose to the
@@ -641,9 +641,9 @@ static int launch_wgrad(WgradParams& p, hipStream_t stream) {
   const double flops = 2.0 * (double)p.M * (double)p.K * (double)p.C * (double)p.R * (double)p.S;
   const int G = (!ring && groups == 2 && p.plain && flops < 40e9) ? 2 : 1;
   const int smem = ring ? WG_RING_STAGES * 32 * (TK + TN) * 2 : G * 2 * 64 * (TK + TN) * 2;
-  static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_BLOCKS"); return e ? atoi(e) : 0; }();
+  constexpr int cap_env = 0;
   const int max_cu = 4 / G;                                                   // 16 waves per CU at most
-  static const int lds_budget = [] { const char* e = getenv("DDL_WGRAD_LDS_KB"); return e ? atoi(e) : 160; }();
+  constexpr int lds_budget = 160;
   int per_cu = (lds_budget * 1024) / smem < max_cu ? (lds_budget * 1024) / smem : max_cu;   // LDS- and register-limited residency
   if (per_cu < 1) per_cu = 1;
   const long long capacity = cap_env > 0 ? cap_env : 256 * per_cu;
@@ -675,7 +675,7 @@ static int launch_wgrad_fold(WgradParams& p, hipStream_t stream) {
   constexpr bool FOLD = true;
   p.tiles_k = 1; p.tiles_n = 1;
   const int smem = WG_RING_STAGES * 32 * (TK + TN * NSUB) * 2;          // 2 blocks per CU at 4 stages
-  static const int cap_env = [] { const char* e = getenv("DDL_WGRAD_FOLD_BLOCKS"); return e ? atoi(e) : 512; }();
+  constexpr int cap_env = 512;
   long long splits = cap_env;
   const long long max_splits = (p.M + 255) / 256;
   if (splits > max_splits) splits = max_splits;
@@ -728,10 +728,10 @@ static int wgrad_dispatch(WgradParams& p, hipStream_t st) {
   // Wide [128][256] tiles, ONE block per CU (256 resident blocks): the same bytes in flight as two 128 x 128 blocks with
   // 25 % less LDS and fabric traffic per MFMA.  Alone the filter gradients are no faster this way (8.3 vs 8.2 ms per
   // ResNet-50 step); next to the data-gradient / BatchNorm chain of the main stream, which is where they run, the step
-  // gains 0.8 ms of 37.4 (bench/ab_wide_caps.sh).  DDL_WGRAD_WIDE=0 restores 128 x 128 everywhere.
+  // gains 0.8 ms of 37.4 (docs/STATUS.md, round 2).  DDL_WGRAD_WIDE=0 restores 128 x 128 everywhere.
   static const int wide_on = [] { const char* e = getenv("DDL_WGRAD_WIDE"); return e ? atoi(e) : 1; }();
-  static const int wide_pad = [] { const char* e = getenv("DDL_WGRAD_WIDE_PAD"); return e ? atoi(e) : 0; }();
-  static const int wide_cap = [] { const char* e = getenv("DDL_WGRAD_WIDE_CAP"); return e ? atoi(e) : 256; }();
+  constexpr int wide_pad = 0;
+  constexpr int wide_cap = 256;
   const int sc_pad = (p.SC + 255) / 256 * 256;
   const bool wide_fit = K % 128 == 0 && (p.SC % 256 == 0 || (wide_pad && p.SC >= 256 && sc_pad * 100 <= p.SC * 115));
   if (wide_on && wide_fit && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)

@@ -24,7 +24,6 @@ _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
 _SIGS = {
     "ddl_conv_igemm": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp] + [_i] * 13 + [_vp],
-    "ddl_conv_fwd_inbn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp, _ll, _vp],
     "ddl_conv_wgrad_plan": [_i] * 11,
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],

@@ -122,24 +122,6 @@ def conv2d_fwd_bn(x, w_krsc, stride, pad, gamma, beta, running_mean, running_var
     return y, vec
 
 
-def conv1x1_fwd_inbn(z, w_krsc, in_scale, in_shift, slab=None):
-    """``conv1x1(relu(z * in_scale + in_shift), w)`` with the producer's BatchNorm + ReLU applied to the input
-    fragments INSIDE the kernel (``csrc/conv_ring.hip``, EPI bit 8): ``z`` is a raw conv output, the normalised
-    activation is never materialised.  Returns ``(y, stats slab)`` like ``conv2d_fwd(want_stats=True)``."""
-    lib = _lib.require()
-    _chk_act(z, "conv1x1_fwd_inbn")
-    z = nhwc(z)
-    N, Cc, H, W = z.shape
-    K, R, S, C2 = w_krsc.shape
-    if (R, S) != (1, 1) or C2 != Cc or Cc > 512 or w_krsc.dtype != BF16 or not w_krsc.is_contiguous():
-        raise ValueError("conv1x1_fwd_inbn: needs a contiguous bf16 [K,1,1,C] filter with C <= 512")
-    y = torch.empty((N, K, H, W), dtype=BF16, device=z.device, memory_format=CL)
-    stats = slab if slab is not None else new_slab(K, z.device)
-    check(lib.ddl_conv_fwd_inbn(ptr(z), ptr(w_krsc), ptr(y), ptr(stats), ptr(in_scale), ptr(in_shift), N, H, W, Cc, K,
-                                stream_ptr()), "conv1x1_fwd_inbn")
-    return y, stats
-
-
 # ------------------------------------------------------------------------------- channel windows (dense blocks)
 class ChannelWindow:
     """Channels ``[c0, c0 + c)`` of a bf16 NHWC buffer ``[N, Ctot, H, W]`` (channels_last) — what a dense block's

@@ -272,8 +272,12 @@ class Trainer:
         out = self._graph_step(x, y)
         if out is not None:
             return out
-        loss, correct = self._forward_loss(x, y)
-        loss.backward()
+        if isinstance(self.model, PipelinedModel) and self.cfg.pipeline_schedule == "1f1b":
+            # every micro-batch's backward is issued as it leaves the last stage (parallel/pipeline.py)
+            loss, correct = self.model.train_step(x, y, self.criterion, reducers=self.ddps)
+        else:
+            loss, correct = self._forward_loss(x, y)
+            loss.backward()
         di = 0
         for d in self.ddps:
             if d is None:

@@ -242,6 +242,18 @@ def test_persistent_ring_kernel_matches_fp32(env):
     assert "0 failed" in r.stdout
 
 
+@pytest.mark.parametrize("mode", ["2", "1"], ids=["everything-it-can-run", "default-selection"])
+def test_big_tile_ping_pong_kernel_matches_fp32(mode):
+    """csrc/conv_big.hip (256 x 256 tiles, two wave groups half a K-step apart, 128-byte LDS rows, persistent tiles,
+    image-boundary split of a thin last tile round) against plain fp32 PyTorch on ragged shapes: forward + statistics
+    (1x1, 3x3, strided), plain dgrad, dgrad with a masked / plain addend, and grids of 2 rounds + 18 tiles that the
+    launcher cuts between this kernel and the ring kernels.  ``DDL_CONV_BIG`` is read once per process: child."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench", "big_probe.py"), "64", "parity", "child"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ, DDL_CONV_BIG=mode))
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert "0 failed" in r.stdout and "FAIL" not in r.stdout
+
+
 # --------------------------------------------------------------------------------------------- Linear on our GEMM
 @pytest.mark.parametrize("B,fin,fout,relu,bias", [(128, 2048, 1000, False, True), (32, 25088, 4096, True, True),
                                                   (100, 400, 120, True, True), (9, 84, 10, False, True),
@@ -396,30 +408,6 @@ def test_conv1d_k1_relu_front_matches_torch(B):
     (conv(x) * (y.detach().float() > 0)).backward(dy.float())       # same gate as the kernel's own bf16 output
     _close(gw, conv.weight.grad, rtol=1e-2, atol=1e-2 * conv.weight.grad.abs().max().item(), what="conv1d dW")
     _close(gb, conv.bias.grad, rtol=1e-2, atol=1e-2 * conv.bias.grad.abs().max().item(), what="conv1d db")
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("N,C,HW,Kc", [(32, 64, 56, 256), (16, 128, 28, 512), (8, 72, 14, 96), (4, 512, 7, 2048)])
-def test_conv1x1_with_input_batchnorm_applied_in_the_kernel_matches_fp32(N, C, HW, Kc):
-    """The bn2 -> conv3 fusion experiment (bench/inbn_probe.py, docs/STATUS.md): scale/shift/ReLU applied to the raw
-    producer output inside the ring kernel; y and its BatchNorm statistics against plain fp32."""
-    from distributed_deep_learning_amd.ops import kernels as K
-
-    dev = _dev()
-    g = torch.Generator().manual_seed(11)
-    z = _rand_act((N, C, HW, HW), 12)
-    w = (torch.randn((Kc, C, 1, 1), generator=g) / C ** 0.5).to(dev)
-    scale = (torch.rand(C, generator=g) + 0.5).to(dev)
-    shift = (torch.randn(C, generator=g) * 0.3).to(dev)
-    wk, _ = K.filter_repack(w.contiguous(memory_format=CL))
-    y, slab = K.conv1x1_fwd_inbn(z, wk, scale, shift)
-    a = F.relu(z.float() * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)).to(torch.bfloat16).float()
-    ref = F.conv2d(a, wk.float().permute(0, 3, 1, 2))
-    _close(y, ref, what="conv1x1_fwd_inbn y")
-    sums = K.slab_sums(slab)
-    n = N * HW * HW
-    _close(sums[0] / n, ref.mean((0, 2, 3)), what="conv1x1_fwd_inbn mean")
-    _close(sums[1] / n, (ref * ref).mean((0, 2, 3)), what="conv1x1_fwd_inbn mean square")
 
 
 def _dense_layers(c0, growth, nlayers, bn_size, dev, seed):

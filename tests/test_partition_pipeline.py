@@ -90,6 +90,66 @@ def test_pipeline_backward_matches_sequential():
         assert torch.allclose(g, p.grad, atol=1e-5)
 
 
+@pytest.mark.parametrize("stages", [1, 2, 3, 4])
+@pytest.mark.parametrize("chunks", [1, 2, 3, 5, 8, 13])
+def test_1f1b_issue_order(stages, chunks):
+    """Every chunk's backward directly follows the tick of its last forward; never more than ``stages`` chunks between
+    their first forward and their backward (GPipe keeps all of them)."""
+    from distributed_deep_learning_amd.parallel.pipeline import schedule_1f1b
+    ops = schedule_1f1b(chunks, stages)
+    assert [c for k, _, c in ops if k == "B"] == list(range(chunks))
+    assert sorted((s, c) for k, s, c in ops if k == "F") == [(s, c) for s in range(stages) for c in range(chunks)]
+    live, peak, seen_last = set(), 0, set()
+    for k, s, c in ops:
+        if k == "F":
+            live.add(c)
+            if s == stages - 1:
+                seen_last.add(c)
+        else:
+            assert c in seen_last
+            live.discard(c)
+        peak = max(peak, len(live))
+    assert peak <= min(stages, chunks)
+
+
+@pytest.mark.parametrize("mb", [1, 3, 4, 8])
+def test_1f1b_train_step_matches_whole_batch_gradients(mb):
+    """``PipelinedModel.train_step``: sample-weighted mean of the micro-batch losses, gradients accumulated over the
+    micro-batches == one backward of the whole batch (no BatchNorm in the MLP); hits are summed; at most ``stages``
+    micro-batches alive."""
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    torch.manual_seed(1)
+    m = models.build("mlp_ref", hidden_layers=2)
+    x = torch.randn(10, 48)
+    y = torch.randint(0, 3, (10,))
+    crit = SoftmaxCrossEntropyLoss()
+    ref_loss = crit(m(x), y)
+    ref_hits = float(crit.last_correct)
+    ref_loss.backward()
+    ref = [p.grad.clone() for p in m.parameters()]
+    m.zero_grad()
+    pm = PipelinedModel(m, [CPU, CPU, CPU], micro_batch=mb)
+    loss, hits = pm.train_step(x, y, crit)
+    assert abs(float(loss) - float(ref_loss)) < 1e-5 and float(hits) == ref_hits
+    assert pm.max_live_chunks <= 3
+    for g, p in zip(ref, m.parameters()):
+        assert torch.allclose(g, p.grad, atol=1e-5)
+
+
+def test_trainer_pipeline_schedules_agree():
+    """-m pipeline: the 1F1B-style default and the reference's GPipe order train the same model to the same weights."""
+    from distributed_deep_learning_amd.config import Config
+    from distributed_deep_learning_amd.trainer import Trainer
+    w = {}
+    for sched in ("1f1b", "gpipe"):
+        cfg = Config(model="mlp", mode="pipeline", stages=2, epochs=1, batch=16, samples=160, optimizer="sgd", lr=0.05,
+                     graph=False, pipeline=4, pipeline_schedule=sched)
+        t = Trainer(cfg, printer=lambda *_: None).setup()
+        t.fit()
+        w[sched] = torch.cat([v.detach().flatten().float() for _, v in sorted(t.model.state_dict().items())])
+    assert torch.allclose(w["1f1b"], w["gpipe"], atol=1e-5)
+
+
 def test_bad_arguments_raise():
     m = models.build("mlp_ref")
     with pytest.raises(TypeError):
