@@ -256,6 +256,15 @@ class DistributedDataParallel(tnn.Module):
             self.ncomm = None
             self.comm_note = (self.comm_note or "native communicator failed its start-up check on some rank") + \
                 "; collectives go through torch.distributed"
+            # the control plane is gloo: staging every bucket through the host would be a rehearsal transport, not a
+            # fallback.  All ranks agreed on the verdict above, so all of them open an RCCL group inside c10d now.
+            if self.on_gpu and self.backend == "gloo" and td.is_nccl_available():
+                try:
+                    self.pg = td.new_group(backend="nccl")
+                    self.backend, self.staged = "nccl", False
+                    self.comm_note += " (nccl group opened beside the gloo control plane)"
+                except Exception as e:          # noqa: BLE001 - keep the host-staged path rather than die here
+                    self.comm_note += f" (no nccl group either: {e!r}; host-staged gloo)"
             if self.rank == 0:
                 print(f"[ddp] {self.comm_note}", file=sys.stderr, flush=True)
 

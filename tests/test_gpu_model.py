@@ -477,6 +477,51 @@ def test_hip_graph_captures_native_collectives(mode):
         td.destroy_process_group()
 
 
+def test_failed_native_communicator_falls_back_to_an_nccl_group_not_to_host_staging(monkeypatch):
+    """Control plane gloo, data plane native RCCL: when the native communicator cannot be opened (here: its constructor
+    raises) every rank learns the verdict through the control plane and the reducer opens an RCCL group inside
+    ``torch.distributed`` for the gradients - not the host-staged gloo rehearsal transport."""
+    import os
+    import torch.distributed as td
+    from distributed_deep_learning_amd import dist as ddist
+    from distributed_deep_learning_amd import models
+    from distributed_deep_learning_amd.nn import SoftmaxCrossEntropyLoss
+    from distributed_deep_learning_amd.optim import FusedSGD
+    from distributed_deep_learning_amd.parallel import DistributedDataParallel, native_comm
+
+    def broken(self, *a, **k):
+        raise RuntimeError("simulated: librccl refused the communicator")
+
+    monkeypatch.setattr(native_comm.NativeCommunicator, "__init__", broken)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29647", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    ddist.init(ddist.RankInfo(rank=0, world=1), _dev(), force=True, comm="native")
+    d = None
+    try:
+        assert td.get_backend() == "gloo"
+        torch.manual_seed(0)
+        m = models.resnet18_cifar().to(_dev())
+        d = DistributedDataParallel(m, bucket_mb=2, force_collectives=True, comm="native")
+        assert d.ncomm is None and d.backend == "nccl" and not d.staged and "nccl group" in d.comm_note
+        o = FusedSGD(d.arena, lr=0.02, momentum=0.9)
+        d.attach(o)
+        crit = SoftmaxCrossEntropyLoss()
+        x = torch.randn(32, 3, 32, 32, device=_dev())
+        y = torch.randint(0, 10, (32,), device=_dev())
+        losses = []
+        for _ in range(6):
+            loss = crit(d(x), y)
+            loss.backward()
+            d.step(o)
+            losses.append(float(loss.detach()))
+        assert losses[-1] < losses[0], losses
+        cs = d.param_checksum()
+        assert torch.equal(cs, cs[0:1].expand_as(cs))
+    finally:
+        if d is not None:
+            d.close()
+        td.destroy_process_group()
+
+
 def test_ledger_snapshot_on_vgg_chain_and_lenet():
     """The conv-ReLU chain writes bias gradients from the NEXT unit's dgrad epilogue (slab fold into the arena) and
     filter gradients on the side stream: the ledger's bucket snapshots prove that every one of them has landed before
