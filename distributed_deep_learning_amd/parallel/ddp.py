@@ -38,6 +38,7 @@ from __future__ import annotations
 
 import collections
 import datetime
+import inspect
 import os
 import sys
 import threading
@@ -147,10 +148,16 @@ class _HostStagedWork:
 
 class DistributedDataParallel(tnn.Module):
     def __new__(cls, *args, **kwargs):
-        mode = kwargs.get("mode", args[2] if len(args) > 2 else "allreduce")
-        if cls is DistributedDataParallel and mode == "ps":
-            from .ps import ShardedDataParallel
-            return super().__new__(ShardedDataParallel)
+        # DistributedDataParallel(module, mode="ps") builds the sharded subclass: ``mode`` is read through the constructor's
+        # own signature, wherever the caller put it
+        if cls is DistributedDataParallel:
+            try:
+                mode = inspect.signature(cls.__init__).bind_partial(None, *args, **kwargs).arguments.get("mode", "allreduce")
+            except TypeError:
+                mode = "allreduce"                      # bad arguments: let __init__ raise the real error
+            if mode == "ps":
+                from .ps import ShardedDataParallel
+                return super().__new__(ShardedDataParallel)
         return super().__new__(cls)
 
     def __init__(self, module: tnn.Module, bucket_mb: float = 32.0, mode: str = "allreduce",
