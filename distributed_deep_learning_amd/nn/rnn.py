@@ -13,7 +13,6 @@ import torch.nn as tnn
 
 from ..ops import kernels as K
 from ..ops import state as _state
-from ..ops import streams
 
 BF16 = torch.bfloat16
 
@@ -22,11 +21,12 @@ def _wgrad_rows(g2: torch.Tensor, x2: torch.Tensor, weight: torch.Tensor):
     """``g2^T @ x2`` for ``g2 [M, K]``, ``x2 [M, C]`` (bf16, M = B*T huge, K and C small) in fp32 ``[K, C]``.  This
     tall-skinny reduction is exactly a 1x1 convolution's filter gradient over M "pixels": the split-M MFMA kernel
     (``ops.kernels.gemm_tn``) spreads it over the whole chip.  A parameter that lives in an arena gets the product
-    accumulated straight into its gradient there, on the wgrad side stream (returns ``None`` for autograd)."""
+    accumulated straight into its gradient there (returns ``None`` for autograd) - on the CURRENT stream: forking these
+    15-80 us GEMMs to the wgrad side stream was measured on the reference's LSTM workload and costs more than it hides
+    (hipGraph step 0.480 -> 0.543 ms at batch 32, 0.997 -> 1.046 ms at batch 4096: ``bench/ref_workloads.py``)."""
     arena = getattr(weight, "_ddl_arena", None)
     if arena is not None and arena.grad_is_arena_view(weight) and weight.grad.is_contiguous():
-        with streams.fork(g2, x2):
-            K.gemm_tn(g2, x2, weight.grad)
+        K.gemm_tn(g2, x2, weight.grad)
         arena.notify_grad_ready(weight)
         return None
     dw = torch.zeros((g2.shape[1], x2.shape[1]), dtype=torch.float32, device=g2.device)
@@ -37,7 +37,7 @@ class LSTMLayerFn(torch.autograd.Function):
     """``out[B,T,H] (bf16) = LSTM(x[B,T,I])`` with zero initial state, PyTorch gate order i, f, g, o.  ``w_*16`` are
     the bf16 weights, ``w_*16_t`` their ``[in, 4H]`` transposes (the arena's shadow pairs when the parameters live
     there).  Backward: the fused recurrent kernel for the gate gradients, then the two weight gradients on the
-    split-M MFMA kernel (side stream, straight into the arena) and the input gradient on the row GEMM of
+    split-M MFMA kernel (straight into the arena) and the input gradient on the row GEMM of
     ``csrc/lstm.hip`` - no library GEMM."""
 
     @staticmethod
