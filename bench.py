@@ -194,7 +194,37 @@ def run_sweep(a, argv) -> int:
 
 
 # ----------------------------------------------------------------------------------------------- one rank
+class _QuietStdout:
+    """Everything that libraries write to file descriptor 1 while a rank runs (gloo's connection line, RCCL's version
+    banner, ...) goes to stderr: the driver contract is ONE JSON line on stdout.  ``restore()`` gives fd 1 back."""
+
+    def __init__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def emit(self, line: str) -> None:
+        """Write one line to the REAL stdout."""
+        sys.stdout.flush()
+        os.write(self.saved if self.saved is not None else 1, (line + "\n").encode())
+
+    def restore(self) -> None:
+        if self.saved is not None:
+            sys.stdout.flush()
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+            self.saved = None
+
+
 def run_rank(a) -> int:
+    quiet = _QuietStdout()
+    try:
+        return _run_rank(a, quiet)
+    finally:
+        quiet.restore()
+
+
+def _run_rank(a, quiet) -> int:
     import torch
     import torch.distributed as td
 
@@ -355,7 +385,7 @@ def run_rank(a) -> int:
             "final_loss": round(final_loss, 4),
             "note": "reference publishes no numbers (BASELINE.md); comparator = stock PyTorch-ROCm measured on the same MI355X",
         }
-        print(json.dumps(rec), flush=True)
+        quiet.emit(json.dumps(rec))
     if ddp is not None:
         ddp.close()
     ddist.shutdown()
