@@ -78,6 +78,10 @@ def init(info: Optional[RankInfo] = None, device: Optional[torch.device] = None,
     os.environ.setdefault("MASTER_PORT", "29500")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = backend_for(device or torch.device("cpu"), comm)
+    if backend == "gloo" and os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1") and os.path.isdir("/sys/class/net/lo"):
+        # single-node rendezvous on the loopback address: gloo otherwise picks its interface by resolving the hostname,
+        # which containers often cannot do
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     kwargs = {}
     if backend == "nccl" and device is not None and bind_device:
         kwargs["device_id"] = device
