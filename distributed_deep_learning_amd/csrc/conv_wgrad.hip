@@ -545,6 +545,277 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_ring_kernel(const WgradPar
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// "Halo" kernel: stride-1 filters with several taps (the 3x3 convs of ResNet / VGG, the 4x4 filter of the
+// space-to-depth stem).  The ring kernel above treats every tap as its own GEMM column block, so a block streams x once
+// per tap it owns and dy once per (filter row, column block): per 32-pixel step a 128 x 256 tile pulls 24 KiB through the
+// L2 -> LDS path for 512 MFMA clocks, 47 B/clk per CU, and that path delivers ~27 B/clk per CU (bench/wgrad_ablate.py: the
+// kernel with its MFMAs and fragment reads compiled out runs 60-85 % as long as the full one on the 3x3 layers).
+// Here a block owns ALL taps of a [TK filters] x [TC input channels] slice.  A stage is a group of whole output rows
+// (TR rows of one image, or G whole small images: <= 224 pixels = 7 MFMA steps of 32) staged ONCE together with the
+// input rows they touch INCLUDING the halo ((TR + R - 1) x (Q + S - 1) positions, zero outside the image); every tap
+// then reads the same LDS tile at a shifted position - the transposing LDS read takes one address per lane, so a shift
+// is just an address offset.  L2 -> LDS bytes per MFMA drop 2.5x (14 x 14 x 256: 65 KiB per 4032 MFMA clocks).
+//   dy tile  [224 rows][TK] with tr_off's swizzle; LDS row rho of a 32-row step holds pixel 4*(rho>>3) + (rho&3) +
+//            16*((rho>>2)&1) of the step - a permutation of the reduction order that makes the 16 rows one x-read
+//            touches CONSECUTIVE pixels (both operands use the same order, so the sum is unchanged);
+//   x tile   one sub-tile [positions][16 channels] (32-byte rows, no swizzle needed: a wave-read is 512 contiguous
+//            bytes) per 16-channel block.
+// Two stages in LDS: stage t+1 is fetched (LDS-DMA, spread over the 7 steps) while stage t is multiplied; one barrier
+// per stage.  Waves: WKS x WNS = 4, each 64 filters x (all taps x 16 channels) - or, TAPSPLIT (stem, 16 channels in
+// all), 64 filters x (one filter row's taps x 16 channels).
+struct HaloGeom {
+  int G, TR, XR, Wp, XPOS, NV;        // images / output rows per stage, input rows per image, padded row length, positions, 1 KiB slices per sub-tile
+  int nrb, nst, sps;                  // row blocks per image, stages in all, stages per split
+  int px;                             // pixels per full stage (G * TR * Q)
+  int xsub, stage_bytes;              // bytes of one x sub-tile / of one stage
+  FastDiv div_xrwp, div_wp, div_nrb;
+};
+
+template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS>
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams p, const HaloGeom hg) {
+  constexpr int KS = 7, TK = 64 * WKS, TAPS = R_ * S_;
+  constexpr int NCB = TAPSPLIT ? 1 : WNS;               // 16-channel blocks per tile
+  constexpr int TC = 16 * NCB;
+  constexpr int FK = 4, FN = TAPSPLIT ? TAPS / WNS : TAPS;
+  constexpr int YROWB = TK * 2, YRW = 1024 / YROWB;     // dy rows per LDS-DMA instruction (4 or 8)
+  constexpr int NYW = KS * 32 / YRW / 4;                // dy instructions per wave per stage (14 or 7)
+  constexpr int NDMA = NYW + XS;                        // LDS-DMA instructions per wave per stage (XS: x slices, some may be idle)
+  constexpr int PD = 3;                                 // the fragment reads run PD taps ahead of the MFMAs
+  constexpr int YBYTES = KS * 32 * YROWB;
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  static_assert(WKS * WNS == 4 && NDMA <= (KS - 3) * FN && PD < FN, "four waves; the next stage is requested early in this one");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wk = (WKS == 2) ? (wid & 1) : 0, wn = (WKS == 2) ? (wid >> 1) : wid;
+
+  unsigned b = xcd_remap(blockIdx.x, gridDim.x);
+  const int tc = b % p.tiles_n; b /= p.tiles_n;
+  const int tk = b % p.tiles_k; b /= p.tiles_k;
+  const int split = (int)b;
+  const int k0 = tk * TK, c0 = tc * TC;
+  const int st_begin = split * hg.sps;
+  const int st_end = min(hg.nst, st_begin + hg.sps);
+
+  const u32x4 ysrc = wg_make_rsrc(p.dy, p.dy_bytes);
+  const u32x4 xsrc = wg_make_rsrc(p.x, p.x_bytes);
+  const unsigned smem_addr = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+
+  // ---- load slots.  One wave, one SIMD, in-order issue: whatever address arithmetic a load needs is time the MFMA pipe
+  //      idles, so everything that does not change from stage to stage is decoded ONCE, here.
+  // dy: instruction u = e*4 + wid fills LDS rows u*YRW .. +YRW-1 (the row bits tr_off swizzles with are per-thread
+  // constants, as in the ring kernel); yrel = byte offset of the lane's 16 bytes from the stage's first pixel.
+  const unsigned krow2 = (unsigned)p.K * 2u;
+  unsigned yrel[NYW];
+  {
+    const int yrow = lane / (YROWB / 16), yphys = lane % (YROWB / 16);
+    int ych;
+    if (TK == 128) ych = yphys ^ (((yrow & 3) << 2) | (wid & 3));
+    else           ych = yphys ^ ((((yrow >> 1) & 1) << 1) | ((wid & 1) << 2));
+#pragma unroll
+    for (int e = 0; e < NYW; ++e) {
+      const int row = (e * 4 + wid) * YRW + yrow;
+      const int rr = row & 31;
+      const int j = (row & ~31) + 4 * (rr >> 3) + (rr & 3) + 16 * ((rr >> 2) & 1);     // pixel of the stage in this LDS row
+      yrel[e] = (unsigned)j * krow2 + (unsigned)(k0 + ych * 8) * 2u;
+    }
+  }
+  // x: slice w = wid + 4k of the NCB * NV slices of a stage: 32 positions x 16 channels.  xrel = byte offset from input
+  // pixel (n0, p0, 0) (may be negative: halo), xdyn = what the per-stage range check needs (input row, or image of the
+  // group when a stage holds whole images), 0x40000000 when the position can never be valid.
+  const int NXT = NCB * hg.NV;
+  unsigned xrel[XS], xlds[XS];
+  int xdyn[XS];
+#pragma unroll
+  for (int k = 0; k < XS; ++k) {
+    const int w = wid + 4 * k;
+    int cb = 0;
+    if (NCB > 1) cb = (w >= hg.NV) + (w >= 2 * hg.NV) + (w >= 3 * hg.NV);
+    const int v = w - cb * hg.NV;
+    const unsigned pos = (unsigned)(v * 32 + (lane >> 1));
+    const unsigned gi = fastdiv(pos, hg.div_xrwp);
+    const unsigned rem = pos - gi * hg.div_xrwp.d;
+    const unsigned i = fastdiv(rem, hg.div_wp);
+    const int iw = (int)(rem - i * hg.div_wp.d) - p.pad;
+    const int ihr = (int)i - p.pad;                                 // input row relative to p0
+    const bool st_ok = w < NXT && (int)pos < hg.XPOS && (unsigned)iw < (unsigned)p.W &&
+                       (hg.G == 1 || (unsigned)ihr < (unsigned)p.H);
+    xrel[k] = (unsigned)((((int)gi * p.H + ihr) * p.W + iw) * p.C + c0 + cb * 16 + (lane & 1) * 8) * 2u;
+    xdyn[k] = st_ok ? (hg.G == 1 ? ihr : (int)gi) : 0x40000000;
+    // idle slots (w >= NXT) zero-fill a 1 KiB scratch slice behind the two stages
+    xlds[k] = w < NXT ? (unsigned)(YBYTES + cb * hg.xsub + v * 1024) : 0xFFFFFFFFu;
+  }
+  const unsigned dummy_lds = smem_addr + (unsigned)(2 * hg.stage_bytes);
+
+  // per-stage scalars of the stage being fetched
+  unsigned l_sb = 0, l_ybase = 0, l_ylim = 0, l_xbase = 0;
+  int l_dyn0 = 0, l_dynlim = 0;
+  auto begin_stage = [&](int st, int bufi) {
+    const int ig = (int)fastdiv((unsigned)st, hg.div_nrb);
+    const int rb = st - ig * hg.nrb;
+    const int n0 = ig * hg.G, p0 = rb * hg.TR;
+    l_sb = smem_addr + (unsigned)(bufi * hg.stage_bytes);
+    l_ybase = (unsigned)((n0 * p.P + p0) * p.Q) * krow2;
+    l_ylim = (unsigned)(min(hg.G, p.N - n0) * min(hg.TR, p.P - p0) * p.Q) * krow2;
+    l_xbase = (unsigned)((n0 * p.H + p0) * p.W * p.C) * 2u;
+    l_dyn0 = hg.G == 1 ? p0 : n0;
+    l_dynlim = hg.G == 1 ? p.H : p.N;
+  };
+  auto issue_slot = [&](int slot) {                                 // slot: compile-time after unrolling
+    if (slot < NYW) {
+      wg_lds_dma16(ysrc, l_sb + (unsigned)((slot * 4 + wid) * 1024), yrel[slot] < l_ylim ? l_ybase + yrel[slot] : OOB);
+    } else {
+      const int k = slot - NYW;
+      const bool ok = (unsigned)(l_dyn0 + xdyn[k]) < (unsigned)l_dynlim;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(xlds[k]);
+      wg_lds_dma16(xsrc, dst == 0xFFFFFFFFu ? dummy_lds : l_sb + dst, ok ? l_xbase + xrel[k] : OOB);
+    }
+  };
+
+  f32x4 acc[FK][FN];
+#pragma unroll
+  for (int i = 0; i < FK; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment-read geometry.  Reduction slot (g, e = q + 4h) of a step is LDS row 8g + e of dy and pixel 4g + q + 16h.
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, pp4 = lane & 3;
+  int posb[KS][2];                                                  // byte offset of the lane's x row, per step and half
+  {
+    const int trq = hg.TR * p.Q;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        int j = ks * 32 + 4 * g + q4 + 16 * h;
+        if (j >= hg.px) j = hg.px - 1;                              // slots past the stage: dy is zero there, any finite x does
+        const int gi = j / trq, jr = j - gi * trq;
+        const int pr = jr / p.Q, qq = jr - pr * p.Q;
+        posb[ks][h] = ((gi * hg.XR + pr) * hg.Wp + qq) * 32 + pp4 * 8;
+      }
+  }
+  const int wp32 = hg.Wp * 32;
+
+  if (st_begin < st_end) {
+    begin_stage(st_begin, 0);
+#pragma unroll
+    for (int slot = 0; slot < NDMA; ++slot) issue_slot(slot);
+  }
+  int buf = 0;
+  for (int st = st_begin; st < st_end; ++st) {
+    wg_wait_vmcnt<0>();                          // this wave's slices of stage st have landed ...
+    __builtin_amdgcn_s_barrier();                // ... everybody's have, and nobody reads the other buffer any more
+    asm volatile("" ::: "memory");
+    const bool more = st + 1 < st_end;
+    begin_stage(more ? st + 1 : st, buf ^ 1);
+    if (!more) { l_ylim = 0; l_dynlim = 0; }     // past the last stage every slot zero-fills (no branch in the tap loop)
+    const char* const yb = smem + buf * hg.stage_bytes;
+    const char* const xb = yb + YBYTES + (TAPSPLIT ? 0 : wn * hg.xsub);
+    auto read_a = [&](int ks, bf16x8 (&a)[FK]) {
+      const int rbase = ks * 32 + 8 * g + q4;
+#pragma unroll
+      for (int i = 0; i < FK; ++i) {
+        const int cc = (wk * 64 + i * 16) >> 3;
+        const int ch = cc + (pp4 >> 1);
+        const int sub = (pp4 & 1) * 8;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(yb + tr_off<TK>(rbase, ch) + sub));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(yb + tr_off<TK>(rbase + 4, ch) + sub));
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        a[i] = __builtin_bit_cast(bf16x8, v);
+      }
+    };
+    auto read_b = [&](int ks, int t) -> bf16x8 {                    // tap t of this wave: (r, s) = (t / S, t % S), or (wn, t)
+      const int toff = TAPSPLIT ? (wn * wp32 + t * 32) : ((t / S_) * wp32 + (t % S_) * 32);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(xb + posb[ks][0] + toff));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+          (__attribute__((address_space(3))) s16x4*)(xb + posb[ks][1] + toff));
+      s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    // One wave per SIMD: nothing else hides LDS latency, so the fragment reads run PD taps ahead of the MFMAs (the next
+    // step's dy fragments ride along with its first tap), pinned in that order for the scheduler; the requests for the
+    // NEXT stage go out one per tap from the first tap on, so the last of them has four steps to land.
+    bf16x8 a0[FK], a1[FK], bq[PD + 1];
+    read_a(0, a0);
+    if (HALO_ABL & 4) { read_a(0, a1); bq[PD] = read_b(0, PD); }
+#pragma unroll
+    for (int t = 0; t < PD; ++t) bq[t] = read_b(0, t);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 (&ac)[FK] = (ks & 1) ? a1 : a0;
+      bf16x8 (&an)[FK] = (ks & 1) ? a0 : a1;
+#pragma unroll
+      for (int t = 0; t < FN; ++t) {
+        const int slot = ks * FN + t;
+#ifndef HALO_ABL
+#define HALO_ABL 0
+#endif
+        if (slot < NDMA && !(HALO_ABL & 1)) issue_slot(slot);
+        const int nks = (slot + PD) / FN, nt = (slot + PD) % FN;     // the tap PD ahead
+        if (nks < KS && !(HALO_ABL & 4)) {
+          if (nt == 0) {
+            read_a(nks, an);
+            bq[(slot + PD) % (PD + 1)] = read_b(nks, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * FK + 2, 0);
+          } else {
+            bq[(slot + PD) % (PD + 1)] = read_b(nks, nt);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          }
+        }
+        if (HALO_ABL & 2) {
+#pragma unroll
+          for (int i = 0; i < FK; ++i) asm volatile("" :: "v"(ac[i]));
+          asm volatile("" :: "v"(bq[slot % (PD + 1)]));
+        } else {
+#pragma unroll
+          for (int i = 0; i < FK; ++i)
+            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bq[slot % (PD + 1)], acc[i][t], 0, 0, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, FK, 0);
+        }
+      }
+    }
+    buf ^= 1;
+  }
+  wg_wait_vmcnt<0>();                             // the zero fills requested during the last stage
+  __syncthreads();                                // all fragment reads done (no load is in flight: the last stage fetched nothing)
+
+  // ---- epilogue: the [TK][TAPS][TC] tile goes through LDS in two passes of TK/2 filters, then out in runs of TC floats
+  if (st_begin < st_end || p.part != nullptr) {
+    constexpr int TNW = TAPS * TC;
+    float* const out = p.part != nullptr ? p.part + (size_t)split * (size_t)p.part_stride : p.dw;
+    float* const Ts = reinterpret_cast<float*>(smem);          // [TK / 2][TNW] fp32 (<= 72 KiB), reuses the stages
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (hh > 0) __syncthreads();
+#pragma unroll
+      for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+        for (int t = 0; t < FN; ++t) {
+          const int col = TAPSPLIT ? (wn * FN + t) * 16 + (lane & 15) : t * TC + wn * 16 + (lane & 15);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int lr = wk * 32 + ii * 16 + (lane >> 4) * 4 + e;
+            Ts[lr * TNW + col] = acc[hh * 2 + ii][t][e];
+          }
+        }
+      __syncthreads();
+      for (int f = tid; f < (TK / 2) * TNW; f += 256) {
+        const int lr = f / TNW, col = f - lr * TNW;
+        const int k = k0 + (lr >> 5) * 64 + hh * 32 + (lr & 31);
+        const int tap = col / TC, c = col - tap * TC;
+        float* const dst = out + ((size_t)k * TAPS + (size_t)tap) * (size_t)p.C + (size_t)(c0 + c);
+        if (p.part != nullptr) *dst = Ts[f];
+        else atomicAdd(dst, Ts[f]);
+      }
+    }
+  }
+}
+
 // dw[e] += sum_s part[s][e] with the splits summed in a FIXED order: split-lane ty of a block adds splits ty, ty + NY, ...
 // front to back, and the NY partial sums are combined in a fixed order through LDS.  NX lanes of 16 bytes side by side:
 // NX = 64 (1 KiB per wave-load) for big filters; NX = 16 with 64 split-lanes for small filters with hundreds of splits
@@ -717,9 +988,65 @@ static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
   return wgrad_finish(p, stream);
 }
 
+// Halo launch (see conv_wgrad_halo_kernel).  Returns -100 when the problem does not fit the kernel's assumptions (the
+// caller then takes the ring kernels).
+template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS>
+static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
+  constexpr int TK = 64 * WKS, NCB = TAPSPLIT ? 1 : WNS, TC = 16 * NCB, KS = 7;
+  if (p.K % TK != 0 || p.C % TC != 0 || p.Q > KS * 32) return -100;
+  HaloGeom hg;
+  const int pq = p.P * p.Q;
+  if (pq <= KS * 32) { hg.TR = p.P; hg.G = (KS * 32) / pq; if (hg.G > p.N) hg.G = p.N; }
+  else               { hg.G = 1; hg.TR = (KS * 32) / p.Q; }
+  hg.px = hg.G * hg.TR * p.Q;
+  if (hg.px < 5 * 32) return -100;                              // more than two of the seven steps would be padding
+  hg.XR = hg.TR + R_ - 1;
+  hg.Wp = p.Q + S_ - 1;
+  hg.XPOS = hg.G * hg.XR * hg.Wp;
+  hg.NV = (hg.XPOS + 31) / 32;
+  hg.xsub = hg.NV * 1024;
+  hg.stage_bytes = KS * 32 * TK * 2 + NCB * hg.xsub;
+  const int smem = 2 * hg.stage_bytes + 1024;                  // + the scratch slice idle load slots zero-fill
+  if (smem > 160 * 1024 || smem < (TK / 2) * R_ * S_ * TC * 4 || (NCB * hg.NV + 3) / 4 > XS) return -100;
+  hg.nrb = (p.P + hg.TR - 1) / hg.TR;
+  hg.nst = ((p.N + hg.G - 1) / hg.G) * hg.nrb;
+  hg.div_xrwp = make_fastdiv((unsigned)(hg.XR * hg.Wp));
+  hg.div_wp = make_fastdiv((unsigned)hg.Wp);
+  hg.div_nrb = make_fastdiv((unsigned)hg.nrb);
+  p.tiles_k = p.K / TK;
+  p.tiles_n = p.C / TC;
+  const long long tiles = (long long)p.tiles_k * p.tiles_n;
+  long long splits = 256 / tiles;
+  if (splits < 1) splits = 1;
+  if (splits > hg.nst) splits = hg.nst;
+  hg.sps = (int)((hg.nst + splits - 1) / splits);
+  splits = (hg.nst + hg.sps - 1) / hg.sps;
+  p.splits = (int)splits;
+  p.m_per_split = hg.sps * hg.px;
+  if (!wgrad_prepare(p)) return 0;
+  static SmemAttrOnce once;
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS>), 160 * 1024);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS>), dim3((unsigned)(tiles * splits)), dim3(256), smem,
+                     stream, p, hg);
+  return wgrad_finish(p, stream);
+}
+
 // The work of ddl_conv_wgrad / ddl_conv_wgrad_plan: fills the problem, picks the tile family, sizes the grid, launches.
 static int wgrad_dispatch(WgradParams& p, hipStream_t st) {
   const int K = p.K, R = p.R;
+  // stride-1 filters with several taps: all taps from one staged tile (DDL_WGRAD_HALO=0: the ring kernels below)
+  static const int halo_on = [] { const char* e = getenv("DDL_WGRAD_HALO"); return e ? atoi(e) : 1; }();
+  if (halo_on && p.stride == 1 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull) {
+    int rc = -100;
+    if (R == 3 && p.S == 3) {
+      if (K % 128 == 0 && p.C % 32 == 0) rc = launch_wgrad_halo<2, 2, 3, 3, false, 6>(p, st);
+      else if (K % 64 == 0 && p.C % 64 == 0) rc = launch_wgrad_halo<1, 4, 3, 3, false, 11>(p, st);
+    } else if (R == 4 && p.S == 4 && p.C == 16 && K % 64 == 0) {
+      rc = launch_wgrad_halo<1, 4, 4, 4, true, 5>(p, st);
+    }
+    if (rc != -100) return rc;
+  }
   // small filters on few channels (the space-to-depth stem: 4 x 4 x 16): all filter rows in one block, dy staged once
   static const int fold_on = [] { const char* e = getenv("DDL_WGRAD_FOLD"); return e ? atoi(e) : 1; }();
   if (fold_on && K <= 64 && R > 1 && R * p.SC <= 256 && R * p.SC > 128 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull)
