@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """Where does a filter-gradient kernel's time go?  Times `ddl_conv_wgrad` from variant builds of csrc/conv_wgrad.hip in
-which parts of the ring kernel's main loop are compiled out (`-DWG_ABL=bits`: 1 = no LDS-DMA refills inside the loop,
-2 = no MFMA, 4 = no transposing fragment reads), on ResNet-50's layer shapes.  The variants compute garbage; only the
-timing is of interest.  Build (CPU box, before the GPU call):
+which parts of the halo kernel's main loop are compiled out (`-DHALO_ABL=bits`: 1 = no LDS-DMA requests inside the
+loop, 2 = no MFMA, 4 = no transposing fragment reads), on ResNet-50's layer shapes.  The variants compute garbage; only
+the timing is of interest.  Build (CPU box, before the GPU call; the variant id is the file name's number):
 
-    cd distributed_deep_learning_amd/csrc && for n in 0 1 2 3 4 5 6 7; do hipcc -O3 -std=c++17 --offload-arch=gfx950 \
-        -fPIC -fno-gpu-rdc -shared -DWG_ABL=$n conv_wgrad.hip -o ../../bench/probes/bin/wg_abl$n.so; done
+    cd distributed_deep_learning_amd/csrc && for n in 0 1 2 3 4 5 7; do hipcc -O3 -std=c++17 --offload-arch=gfx950 \
+        -fPIC -fno-gpu-rdc -shared -DHALO_ABL=$n conv_wgrad.hip -o ../../bench/probes/bin/wg_abl$n.so; done
+
+`DDL_WGRAD_HALO=0` in the environment times the ring kernels instead (every variant then runs the same code).
 
     python bench/wgrad_ablate.py [batch] [variant ids, comma separated: wg_abl<id>.so]
 """
@@ -16,7 +18,8 @@ import sys
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SHAPES = [  # C, H, K, R, stride
+SHAPES = [  # C, H, K, R, stride[, pad]
+    (16, 115, 64, 4, 1, 0),          # the space-to-depth stem
     (64, 56, 64, 3, 1), (128, 28, 128, 3, 1), (256, 14, 256, 3, 1), (512, 7, 512, 3, 1),
     (256, 56, 64, 1, 1), (64, 56, 256, 1, 1), (1024, 14, 256, 1, 1), (256, 14, 1024, 1, 1), (512, 7, 2048, 1, 1),
 ]
@@ -39,8 +42,9 @@ def main() -> int:
     print(f"batch {batch}; ms per call, ring kernel variants", flush=True)
     print(f"{'shape':28s} " + " ".join(f"{names.get(n, 'v%d' % n):>10s}" for n in sorted(libs)), flush=True)
     st = torch.cuda.current_stream(dev).cuda_stream
-    for C, H, K, R, stride in SHAPES:
-        pad = R // 2
+    for shape in SHAPES:
+        C, H, K, R, stride = shape[:5]
+        pad = shape[5] if len(shape) > 5 else R // 2
         P = (H + 2 * pad - R) // stride + 1
         x = torch.randn(batch, H, H, C, device=dev).to(torch.bfloat16)
         dy = torch.randn(batch, P, P, K, device=dev).to(torch.bfloat16)

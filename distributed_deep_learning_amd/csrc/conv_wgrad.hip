@@ -281,6 +281,8 @@ template <int N> __device__ __forceinline__ void wg_wait_vmcnt() {
   else if constexpr (N == 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
   else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
   else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
   else static_assert(N < 0, "unsupported vmcnt");
 }
 
@@ -561,9 +563,20 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad_ring_kernel(const WgradPar
 //            touches CONSECUTIVE pixels (both operands use the same order, so the sum is unchanged);
 //   x tile   one sub-tile [positions][16 channels] (32-byte rows, no swizzle needed: a wave-read is 512 contiguous
 //            bytes) per 16-channel block.
-// Two stages in LDS: stage t+1 is fetched (LDS-DMA, spread over the 7 steps) while stage t is multiplied; one barrier
-// per stage.  Waves: WKS x WNS = 4, each 64 filters x (all taps x 16 channels) - or, TAPSPLIT (stem, 16 channels in
-// all), 64 filters x (one filter row's taps x 16 channels).
+// NB stages in LDS (2; 3 for the stem, whose stages are shorter than a trip to HBM): the stage NB - 1 ahead is requested
+// (LDS-DMA, one instruction per tap from the stage's first tap on) while this one is multiplied; one barrier per stage.
+// Waves: WKS x WNS = 4, each 64 filters x (all taps x 16 channels) - or, TAPSPLIT (stem, 16 channels in all), 64
+// filters x (one filter row's taps x 16 channels).  One wave per SIMD (268 registers), so the loop is written for an
+// in-order machine: everything about a load that does not change per stage is decoded once, the fragment reads run
+// three taps ahead of the MFMAs, and the MFMA is issued with its accumulator tied in place (halo_mfma).
+// Measured, batch 1000 (bench/wgrad_ablate.py): 3x3 x 64 at 56x56 0.50 -> 0.27 ms, 128 at 28x28 0.29 -> 0.25,
+// 256 at 14x14 0.375 -> 0.24, 512 at 7x7 0.42 -> 0.22; the MFMAs alone take 0.157 of those (0.045 of it launch +
+// atomic epilogue), i.e. they run at 95 % of peak when nothing else is in the loop.
+// -DHALO_ABL=bits compiles parts of the main loop out (1: load requests, 2: MFMAs, 4: fragment reads) for
+// bench/wgrad_ablate.py; the library is built with 0.
+#ifndef HALO_ABL
+#define HALO_ABL 0
+#endif
 struct HaloGeom {
   int G, TR, XR, Wp, XPOS, NV;        // images / output rows per stage, input rows per image, padded row length, positions, 1 KiB slices per sub-tile
   int nrb, nst, sps;                  // row blocks per image, stages in all, stages per split
@@ -572,7 +585,16 @@ struct HaloGeom {
   FastDiv div_xrwp, div_wp, div_nrb;
 };
 
-template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS>
+// The MFMA with its accumulator TIED (dst == src C) in the AGPR file.  Through the builtin, hipcc gives the seven
+// unrolled steps' results rotating registers and moves 76 of the 144 accumulator registers back at every stage
+// boundary (v_accvgpr_mov / _write, ~125 per stage, in a burst the MFMA pipe waits for).  The waits for the fragment
+// reads are still the compiler's (it tracks the asm's register operands); no other instruction touches the
+// accumulators between the zero fill and the epilogue, which is fenced below.
+__device__ __forceinline__ void halo_mfma(f32x4& c, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
+template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS, int NB>
 __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams p, const HaloGeom hg) {
   constexpr int KS = 7, TK = 64 * WKS, TAPS = R_ * S_;
   constexpr int NCB = TAPSPLIT ? 1 : WNS;               // 16-channel blocks per tile
@@ -647,7 +669,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
     // idle slots (w >= NXT) zero-fill a 1 KiB scratch slice behind the two stages
     xlds[k] = w < NXT ? (unsigned)(YBYTES + cb * hg.xsub + v * 1024) : 0xFFFFFFFFu;
   }
-  const unsigned dummy_lds = smem_addr + (unsigned)(2 * hg.stage_bytes);
+  const unsigned dummy_lds = smem_addr + (unsigned)(NB * hg.stage_bytes);
 
   // per-stage scalars of the stage being fetched
   unsigned l_sb = 0, l_ybase = 0, l_ylim = 0, l_xbase = 0;
@@ -698,19 +720,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
   }
   const int wp32 = hg.Wp * 32;
 
-  if (st_begin < st_end) {
-    begin_stage(st_begin, 0);
+  // NB stages in LDS, NB - 1 of them requested ahead (stages past the end are all-zero fills, so the counted wait and
+  // the tap loop need no branch).  NB = 3 where a stage is short (the stem: ~1800 MFMA clocks, less than a trip to HBM).
+#pragma unroll
+  for (int a = 0; a < NB - 1; ++a) {
+    begin_stage(min(st_begin + a, hg.nst - 1), a);
+    if (st_begin + a >= st_end) { l_ylim = 0; l_dynlim = 0; }
 #pragma unroll
     for (int slot = 0; slot < NDMA; ++slot) issue_slot(slot);
   }
   int buf = 0;
   for (int st = st_begin; st < st_end; ++st) {
-    wg_wait_vmcnt<0>();                          // this wave's slices of stage st have landed ...
-    __builtin_amdgcn_s_barrier();                // ... everybody's have, and nobody reads the other buffer any more
+    wg_wait_vmcnt<(NB - 2) * NDMA>();            // this wave's slices of stage st have landed ...
+    __builtin_amdgcn_s_barrier();                // ... everybody's have, and nobody reads the buffer of stage st - 1 any more
     asm volatile("" ::: "memory");
-    const bool more = st + 1 < st_end;
-    begin_stage(more ? st + 1 : st, buf ^ 1);
-    if (!more) { l_ylim = 0; l_dynlim = 0; }     // past the last stage every slot zero-fills (no branch in the tap loop)
+    const bool more = st + NB - 1 < st_end;
+    begin_stage(more ? st + NB - 1 : st, buf == 0 ? NB - 1 : buf - 1);
+    if (!more) { l_ylim = 0; l_dynlim = 0; }
     const char* const yb = smem + buf * hg.stage_bytes;
     const char* const xb = yb + YBYTES + (TAPSPLIT ? 0 : wn * hg.xsub);
     auto read_a = [&](int ks, bf16x8 (&a)[FK]) {
@@ -752,20 +778,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
 #pragma unroll
       for (int t = 0; t < FN; ++t) {
         const int slot = ks * FN + t;
-#ifndef HALO_ABL
-#define HALO_ABL 0
-#endif
         if (slot < NDMA && !(HALO_ABL & 1)) issue_slot(slot);
         const int nks = (slot + PD) / FN, nt = (slot + PD) % FN;     // the tap PD ahead
         if (nks < KS && !(HALO_ABL & 4)) {
-          if (nt == 0) {
-            read_a(nks, an);
-            bq[(slot + PD) % (PD + 1)] = read_b(nks, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * FK + 2, 0);
-          } else {
-            bq[(slot + PD) % (PD + 1)] = read_b(nks, nt);
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          }
+          if (nt == 0) read_a(nks, an);
+          bq[(slot + PD) % (PD + 1)] = read_b(nks, nt);
         }
         if (HALO_ABL & 2) {
 #pragma unroll
@@ -773,15 +790,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
           asm volatile("" :: "v"(bq[slot % (PD + 1)]));
         } else {
 #pragma unroll
-          for (int i = 0; i < FK; ++i)
-            acc[i][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ac[i], bq[slot % (PD + 1)], acc[i][t], 0, 0, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, FK, 0);
+          for (int i = 0; i < FK; ++i) halo_mfma(acc[i][t], ac[i], bq[slot % (PD + 1)]);
         }
+        __builtin_amdgcn_sched_barrier(0);      // taps stay in program order: requests, reads PD taps ahead, MFMAs
       }
     }
-    buf ^= 1;
+    buf = (buf == NB - 1) ? 0 : buf + 1;
   }
-  wg_wait_vmcnt<0>();                             // the zero fills requested during the last stage
+  wg_wait_vmcnt<0>();                             // the zero fills requested during the last stages
+  asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");   // the last MFMAs have written the accumulators before anything reads them
   __syncthreads();                                // all fragment reads done (no load is in flight: the last stage fetched nothing)
 
   // ---- epilogue: the [TK][TAPS][TC] tile goes through LDS in two passes of TK/2 filters, then out in runs of TC floats
@@ -990,7 +1007,7 @@ static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
 
 // Halo launch (see conv_wgrad_halo_kernel).  Returns -100 when the problem does not fit the kernel's assumptions (the
 // caller then takes the ring kernels).
-template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS>
+template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS, int NB>
 static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   constexpr int TK = 64 * WKS, NCB = TAPSPLIT ? 1 : WNS, TC = 16 * NCB, KS = 7;
   if (p.K % TK != 0 || p.C % TC != 0 || p.Q > KS * 32) return -100;
@@ -1006,7 +1023,7 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   hg.NV = (hg.XPOS + 31) / 32;
   hg.xsub = hg.NV * 1024;
   hg.stage_bytes = KS * 32 * TK * 2 + NCB * hg.xsub;
-  const int smem = 2 * hg.stage_bytes + 1024;                  // + the scratch slice idle load slots zero-fill
+  const int smem = NB * hg.stage_bytes + 1024;                  // + the scratch slice idle load slots zero-fill
   if (smem > 160 * 1024 || smem < (TK / 2) * R_ * S_ * TC * 4 || (NCB * hg.NV + 3) / 4 > XS) return -100;
   hg.nrb = (p.P + hg.TR - 1) / hg.TR;
   hg.nst = ((p.N + hg.G - 1) / hg.G) * hg.nrb;
@@ -1025,9 +1042,9 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   p.m_per_split = hg.sps * hg.px;
   if (!wgrad_prepare(p)) return 0;
   static SmemAttrOnce once;
-  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS>), 160 * 1024);
+  const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS, NB>), 160 * 1024);
   if (rc != 0) return rc;
-  hipLaunchKernelGGL((conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS>), dim3((unsigned)(tiles * splits)), dim3(256), smem,
+  hipLaunchKernelGGL((conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS, NB>), dim3((unsigned)(tiles * splits)), dim3(256), smem,
                      stream, p, hg);
   return wgrad_finish(p, stream);
 }
@@ -1040,10 +1057,10 @@ static int wgrad_dispatch(WgradParams& p, hipStream_t st) {
   if (halo_on && p.stride == 1 && p.dy_bytes < 0xFFFF0000ull && p.x_bytes < 0xFFFF0000ull) {
     int rc = -100;
     if (R == 3 && p.S == 3) {
-      if (K % 128 == 0 && p.C % 32 == 0) rc = launch_wgrad_halo<2, 2, 3, 3, false, 6>(p, st);
-      else if (K % 64 == 0 && p.C % 64 == 0) rc = launch_wgrad_halo<1, 4, 3, 3, false, 11>(p, st);
+      if (K % 128 == 0 && p.C % 32 == 0) rc = launch_wgrad_halo<2, 2, 3, 3, false, 6, 2>(p, st);
+      else if (K % 64 == 0 && p.C % 64 == 0) rc = launch_wgrad_halo<1, 4, 3, 3, false, 11, 2>(p, st);
     } else if (R == 4 && p.S == 4 && p.C == 16 && K % 64 == 0) {
-      rc = launch_wgrad_halo<1, 4, 4, 4, true, 5>(p, st);
+      rc = launch_wgrad_halo<1, 4, 4, 4, true, 5, 3>(p, st);
     }
     if (rc != -100) return rc;
   }
