@@ -66,7 +66,8 @@ _PAIR_BN = os.environ.get("DDL_BN_PAIR", "1") != "0"
 # Backward launch order of a conv unit: filter gradient (side stream) BEFORE the data gradient (main stream).  Both read
 # the same output gradient, which the BatchNorm-backward apply pass has just written: launched in this order they run
 # side by side and the second reader finds the tensor in the caches (ResNet-50, batch 512: 38.07 -> 37.40 ms; deferring
-# the filter gradient by one unit instead: 37.55-37.75 ms; by two: 37.9 ms).  DDL_WGRAD_FIRST=0: data gradient first.
+# the filter gradient by one unit instead: 37.55-37.75 ms; by two: 37.9 ms; re-measured with round 3's halo filter-gradient
+# kernels at batch 1000: 68.7 ms as is, 69.1 / 69.2 / 69.1 ms deferred by one / two / three units).  DDL_WGRAD_FIRST=0: data gradient first.
 _WGRAD_FIRST = os.environ.get("DDL_WGRAD_FIRST", "1") != "0"
 # conv + bias + ReLU units (VGG, LeNet): measured the other way round (VGG-16, batch 128: 17.8 ms data gradient first,
 # 18.07 ms filter gradient first - the gated dgrad's epilogue also feeds the NEXT unit's bias gradient), so they keep it

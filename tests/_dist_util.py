@@ -80,7 +80,19 @@ def _entry(rank, world, port, fn, args, q, backend="gloo", comm="native"):
 
 
 def run_ranks(fn, world=2, args=(), backend="gloo", comm="native"):
-    """Run ``fn(rank, world, *args)`` on ``world`` ranks (gloo / CPU or rccl / one GPU each); returns the per-rank results."""
+    """Run ``fn(rank, world, *args)`` on ``world`` ranks (gloo / CPU or rccl / one GPU each); returns the per-rank results.
+    The rendezvous port is found by binding port 0 and releasing it, so another process can take it before rank 0
+    listens on it (seen once on the GPU box: EADDRINUSE): that launch is repeated on a fresh port, up to three times."""
+    for attempt in range(3):
+        try:
+            return _run_ranks_once(fn, world, args, backend, comm)
+        except AssertionError as e:
+            if attempt == 2 or "EADDRINUSE" not in str(e):
+                raise
+    raise AssertionError("unreachable")
+
+
+def _run_ranks_once(fn, world, args, backend, comm):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -93,6 +105,8 @@ def run_ranks(fn, world=2, args=(), backend="gloo", comm="native"):
         if status != "ok":
             for p in procs:
                 p.terminate()
+            for p in procs:
+                p.join(30)
             raise AssertionError(f"rank {rank} failed:\n{out}")
         results[rank] = _unplain(out)
     for p in procs:
