@@ -1,7 +1,7 @@
 """The space-to-depth stem conv (4 x 4 taps x 16 channels -> 64, 115 x 115 -> 112 x 112) in isolation: forward + statistics
 and filter gradient, time per launch and parity against fp32.
 
-    [DDL_RING_UNI=0|1] [DDL_RING_BK=32|64] python bench/stem_probe.py [B]
+    [DDL_CONV_STEM=0|1] [DDL_WGRAD_HALO=0|1] python bench/stem_probe.py [B]
 """
 import os
 import sys

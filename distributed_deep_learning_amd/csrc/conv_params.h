@@ -61,6 +61,10 @@ int ddl_launch_conv_ring(ConvParams& p, int mode, hipStream_t stream);
 bool ddl_conv_pring_supported(const ConvParams& p);
 int ddl_launch_conv_pring(ConvParams& p, int mode, hipStream_t stream);
 
+// conv_stem.hip (space-to-depth stem, forward: the input patch lives in LDS, the filter in registers)
+bool ddl_conv_stem_supported(const ConvParams& p);
+int ddl_launch_conv_stem(ConvParams& p, hipStream_t stream);
+
 // conv_big.hip (256 x 256 block tiles, two wave groups half a K-step apart, persistent: the MFMA-bound layers)
 int ddl_conv_big_shape(const ConvParams& p);
 int ddl_conv_big_split(const ConvParams& p);

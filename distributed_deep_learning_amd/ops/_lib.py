@@ -15,7 +15,8 @@ from pathlib import Path
 import torch
 
 _PKG = Path(__file__).resolve().parent.parent
-LIB_PATH = _PKG / "lib" / "libddl_hip.so"
+# DDL_LIB: another build of the library (a variant with parts compiled out, bench/README.md) instead of the in-tree one
+LIB_PATH = Path(os.environ["DDL_LIB"]) if os.environ.get("DDL_LIB") else _PKG / "lib" / "libddl_hip.so"
 
 _lib = None
 _load_error: Exception | None = None

@@ -46,6 +46,8 @@ CONV_CASES = [
     (4, 8, 14, 14, 16, 5, 1, 0),       # LeNet-5 conv2 (6 -> 16)
     (3, 64, 18, 21, 64, 3, 1, 0),      # unpadded 3x3: output grid smaller than input (filter-gradient cursor wraps)
     (5, 16, 23, 19, 64, 4, 1, 0),      # space-to-depth stem shape, odd sizes (filter rows folded into the column index)
+    (3, 16, 115, 115, 64, 4, 1, 0),    # the space-to-depth stem itself (forward: input patch in LDS, filter in registers)
+    (2, 16, 37, 51, 64, 4, 1, 0),      # same kernel: 34 output rows = 8 x 4 + 2 (half-empty last stage), 48-pixel rows
     (5, 64, 7, 7, 128, 3, 1, 1),       # halo filter gradient: four 7x7 images per stage, the last stage holds one
     (3, 32, 28, 28, 128, 3, 1, 1),     # halo filter gradient: 8 output rows per stage, the last row block of an image half empty
     (2, 64, 30, 50, 64, 3, 1, 1),      # halo filter gradient: 4 rows of 50 per stage (200 of 224 slots), 30 = 7 x 4 + 2
