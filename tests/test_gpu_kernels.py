@@ -86,6 +86,26 @@ def test_conv_fwd_dgrad_wgrad(case):
     _close(dw, dw_ref, rtol=1e-2, atol=1e-2 * scale, what="conv wgrad")
 
 
+@pytest.mark.gpu
+def test_stem_forward_kernel_without_statistics_and_its_fallbacks():
+    """csrc/conv_stem.hip has one instantiation with and one without the BatchNorm sums; a bias or a ReLU in the epilogue
+    is not its business and must take the ring kernels.  All three against fp32."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    x = _rand_act((3, 16, 35, 35), 5)
+    w = (torch.randn((64, 16, 4, 4), generator=torch.Generator().manual_seed(6)) / 16.0).to(_dev()).contiguous(memory_format=CL)
+    wk, _ = K.filter_repack(w)
+    wq = wk.permute(0, 3, 1, 2).float()
+    ref = F.conv2d(x.float(), wq, None, 1, 0)
+    y0, st = K.conv2d_fwd(x, wk, 1, 0, want_stats=False)
+    assert st is None
+    _close(y0, ref, what="stem forward, no statistics")
+    y1, _ = K.conv2d_fwd(x, wk, 1, 0, want_stats=True)
+    assert torch.equal(y0, y1)
+    bias = torch.linspace(-1, 1, 64, device=_dev())
+    y2, _ = K.conv2d_fwd(x, wk, 1, 0, bias=bias, relu=True)
+    _close(y2, F.relu(ref + bias.view(1, -1, 1, 1)), what="stem shape with bias + ReLU (ring kernels)")
+
+
 @pytest.mark.parametrize("case", [(2, 64, 14, 14, 256, 1, 1, 0), (3, 256, 9, 9, 64, 1, 1, 0), (2, 128, 16, 16, 128, 3, 1, 1),
                                   (2, 64, 16, 16, 64, 3, 2, 1)])
 @pytest.mark.parametrize("masked", [False, True])
