@@ -1,4 +1,5 @@
 """utils/: seeding, rocprofv3 command rules, kernel-trace summary, debug ledger."""
+import os
 import sqlite3
 
 import pytest
@@ -77,3 +78,23 @@ def test_native_comm_library_resolves_rccl_at_run_time():
     assert lib.ddl_comm_load(_rccl_path()) == 0
     assert lib.ddl_comm_version() > 20000
     assert lib.ddl_comm_all_reduce(None, None, None, 0, 0, 0, None) != 0      # bad arguments are refused, not crashed on
+
+
+def test_ddl_lib_selects_another_build_of_the_kernel_library(tmp_path):
+    """`DDL_LIB=path` (docs/DEBUG_SWITCHES.md) makes ops/_lib.py bind that file instead of the in-tree library: the way
+    variant builds with parts of a kernel compiled out are timed (bench/stem_abl.sh).  Checked in a child process,
+    because the path is read at import."""
+    import subprocess
+    import sys
+    fake = tmp_path / "libddl_variant.so"
+    code = ("from distributed_deep_learning_amd.ops import _lib; import sys; "
+            "print(_lib.LIB_PATH); sys.exit(0)")
+    env = dict(os.environ, DDL_LIB=str(fake))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == str(fake)
+    env.pop("DDL_LIB")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip().splitlines()[-1].endswith(os.path.join("lib", "libddl_hip.so"))
