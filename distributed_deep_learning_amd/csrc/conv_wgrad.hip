@@ -582,7 +582,7 @@ struct HaloGeom {
   int nrb, nst, sps;                  // row blocks per image, stages in all, stages per split
   int px;                             // pixels per full stage (G * TR * Q)
   int xsub, stage_bytes;              // bytes of one x sub-tile / of one stage
-  FastDiv div_xrwp, div_wp, div_nrb;
+  FastDiv div_xrwp, div_wp, div_nrb, div_trq;
 };
 
 // The MFMA with its accumulator TIED (dst == src C) in the AGPR file.  Through the builtin, hipcc gives the seven
@@ -713,8 +713,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(const WgradParams 
       for (int h = 0; h < 2; ++h) {
         int j = ks * 32 + 4 * g + q4 + 16 * h;
         if (j >= hg.px) j = hg.px - 1;                              // slots past the stage: dy is zero there, any finite x does
-        const int gi = j / trq, jr = j - gi * trq;
-        const int pr = jr / p.Q, qq = jr - pr * p.Q;
+        const int gi = (int)fastdiv((unsigned)j, hg.div_trq), jr = j - gi * trq;
+        const int pr = (int)fastdiv((unsigned)jr, p.div_q), qq = jr - pr * p.Q;
         posb[ks][h] = ((gi * hg.XR + pr) * hg.Wp + qq) * 32 + pp4 * 8;
       }
   }
@@ -1030,6 +1030,7 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   hg.div_xrwp = make_fastdiv((unsigned)(hg.XR * hg.Wp));
   hg.div_wp = make_fastdiv((unsigned)hg.Wp);
   hg.div_nrb = make_fastdiv((unsigned)hg.nrb);
+  hg.div_trq = make_fastdiv((unsigned)(hg.TR * p.Q));
   p.tiles_k = p.K / TK;
   p.tiles_n = p.C / TC;
   const long long tiles = (long long)p.tiles_k * p.tiles_n;
@@ -1038,6 +1039,11 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   if (splits > hg.nst) splits = hg.nst;
   hg.sps = (int)((hg.nst + splits - 1) / splits);
   splits = (hg.nst + hg.sps - 1) / hg.sps;
+  // A block needs a run of stages to pay for its prologue (per-lane read / request geometry) and the cold first stage:
+  // below ~20 stages per block the ring kernels win (swept 0 / 12 / 20 / never on ResNet-18-CIFAR at batch 32 / 128 / 512
+  // and ResNet-50 at batch 256, profiles/r3_wgrad_halo_kernel.txt).
+  constexpr int min_stages = 20;
+  if (hg.sps < min_stages) return -100;
   p.splits = (int)splits;
   p.m_per_split = hg.sps * hg.px;
   if (!wgrad_prepare(p)) return 0;
