@@ -1005,6 +1005,10 @@ static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
   return wgrad_finish(p, stream);
 }
 
+static int g_halo_min_stages = 20;
+// Test hook: the smallest run of stages per block for which the halo kernel is chosen (0: whenever the shape fits).
+extern "C" void ddl_wgrad_halo_min_stages(int n) { g_halo_min_stages = n; }
+
 // Halo launch (see conv_wgrad_halo_kernel).  Returns -100 when the problem does not fit the kernel's assumptions (the
 // caller then takes the ring kernels).
 template <int WKS, int WNS, int R_, int S_, bool TAPSPLIT, int XS, int NB>
@@ -1042,8 +1046,7 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   // A block needs a run of stages to pay for its prologue (per-lane read / request geometry) and the cold first stage:
   // below ~20 stages per block the ring kernels win (swept 0 / 12 / 20 / never on ResNet-18-CIFAR at batch 32 / 128 / 512
   // and ResNet-50 at batch 256, profiles/r3_wgrad_halo_kernel.txt).
-  constexpr int min_stages = 20;
-  if (hg.sps < min_stages) return -100;
+  if (hg.sps < g_halo_min_stages) return -100;
   p.splits = (int)splits;
   p.m_per_split = hg.sps * hg.px;
   if (!wgrad_prepare(p)) return 0;

@@ -329,6 +329,13 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
 _WGRAD_PLANS: dict = {}
 
 
+def set_wgrad_halo_min_stages(n: int = 20) -> None:
+    """Test hook: the shortest run of stages per block for which ``csrc/conv_wgrad.hip`` picks its halo kernel (default 20:
+    small problems keep the ring kernels; 0: whenever the shape fits).  Clears the cached workspace plans."""
+    _lib.require().ddl_wgrad_halo_min_stages(int(n))
+    _WGRAD_PLANS.clear()
+
+
 def _wgrad_workspace(lib, geom, device):
     """Scratch for the split-M partial tiles of one filter-gradient launch in REPRODUCIBLE mode (``ops.state``:
     ``set_deterministic`` / ``DDL_DETERMINISTIC=1`` / ``torch.use_deterministic_algorithms``): ``csrc/conv_wgrad.hip``

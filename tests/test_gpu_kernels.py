@@ -373,6 +373,51 @@ def test_wgrad_is_bit_reproducible_and_accumulates(N, C, H, K, R, stride, pad):
     assert float((fast - a).abs().max()) < 1e-4 * float(a.abs().max()) + 1e-5
 
 
+HALO_CASES = [
+    # N, C, H, W, K, R, pad: what csrc/conv_wgrad.hip's halo kernel is built for, at sizes a test can afford
+    (3, 256, 14, 14, 256, 3, 1),       # one image per stage, 128-filter tiles, 8 channel slices
+    (5, 64, 7, 7, 128, 3, 1),          # four 7x7 images per stage, the last stage holds one
+    (3, 32, 28, 28, 128, 3, 1),        # 8 output rows per stage, the last row block of an image half empty
+    (2, 64, 30, 50, 64, 3, 1),         # 64-filter tiles, 4 rows of 50 per stage (200 of 224 slots), 30 = 7 x 4 + 2
+    (2, 64, 56, 56, 64, 3, 1),         # ResNet-50 layer 1
+    (3, 64, 18, 21, 64, 3, 0),         # unpadded
+    (5, 16, 23, 19, 64, 4, 0),         # space-to-depth stem shape, odd sizes: one filter row per wave, three stages in LDS
+    (2, 16, 115, 115, 64, 4, 0),       # the stem itself
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", HALO_CASES)
+@pytest.mark.parametrize("deterministic", [False, True])
+def test_halo_filter_gradient_matches_fp32(case, deterministic):
+    """The halo filter-gradient kernel is only chosen where a block gets >= 20 stages (batch sizes no test can afford on
+    every shape), so the threshold is lifted for the test: small batches, ragged last stages, both meeting modes."""
+    from distributed_deep_learning_amd.ops import kernels as K
+    from distributed_deep_learning_amd.ops import state
+    N, C, H, W, Kc, R, pad = case
+    x = _rand_act((N, C, H, W), 11)
+    P, Q = H + 2 * pad - R + 1, W + 2 * pad - R + 1
+    dy = _rand_act((N, Kc, P, Q), 12)
+    ref = torch.nn.grad.conv2d_weight(x.float(), (Kc, C, R, R), dy.float(), 1, pad)
+    ring = K.conv2d_wgrad(dy, x, R, R, 1, pad)
+    K.set_wgrad_halo_min_stages(0)
+    state.set_deterministic(deterministic)
+    try:
+        dw = K.conv2d_wgrad(dy, x, R, R, 1, pad)
+        again = K.conv2d_wgrad(dy, x, R, R, 1, pad)
+        acc = torch.ones((Kc, R, R, C), dtype=torch.float32, device=_dev()).permute(0, 3, 1, 2)
+        K.conv2d_wgrad(dy, x, R, R, 1, pad, out=acc)
+    finally:
+        state.set_deterministic(False)
+        K.set_wgrad_halo_min_stages()
+    scale = ref.abs().max().item()
+    _close(dw, ref, rtol=1e-2, atol=1e-2 * scale, what="halo wgrad")
+    _close(dw, ring, rtol=1e-4, atol=1e-4 * scale, what="halo vs ring kernels")
+    _close(acc, dw + 1.0, rtol=1e-5, atol=1e-5 * scale + 1e-6, what="accumulates into out")
+    if deterministic:
+        assert torch.equal(dw, again)
+
+
 # ----------------------------------------------------------------------------------------------- fused LSTM layer
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,T,I,H", [(40, 64, 32, 128), (16, 7, 64, 64), (33, 12, 128, 128), (5, 20, 32, 64)])
