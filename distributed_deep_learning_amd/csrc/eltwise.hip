@@ -1,5 +1,6 @@
 // Element-wise and layout kernels (gfx950): all 16-byte vectorized, grid-stride, <= 2048 blocks.
 #include "common.h"
+#include <stdlib.h>
 #include "host_util.h"
 
 __global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out,
@@ -373,7 +374,11 @@ extern "C" int ddl_stream_proxy(void* buf, long long bytes, int workgroups, int 
   if (workgroups < 1 || workgroups > 1024 || passes < 1 || passes > 16 || bytes < 0 || ((uintptr_t)buf & 15) != 0) return -1;
   const long long n16 = bytes / 16;
   if (n16 == 0) return 0;
-  hipLaunchKernelGGL(stream_proxy_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (u32x4*)buf, n16, passes);
+  // DDL_PROXY_LDS_KB: LDS the proxy's blocks hold while they run (a communication kernel's blocks carry tens of KiB of
+  // staging buffers: a CU that hosts one cannot host a compute block that needs (almost) all 160 KiB)
+  static const int lds_kb = [] { const char* e = getenv("DDL_PROXY_LDS_KB"); const int v = e ? atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+  hipLaunchKernelGGL(stream_proxy_kernel, dim3(workgroups), dim3(256), (size_t)lds_kb * 1024, (hipStream_t)stream, (u32x4*)buf,
+                     n16, passes);
   return (int)hipGetLastError();
 }
 
