@@ -314,6 +314,7 @@ static int launch_any(ConvParams& p, hipStream_t st) {
   p.trace = g_conv_trace;
   const bool bwd_sums = MODE == 1 && p.stats != nullptr;
   if (MODE == 0 && use_ring && p.fin.counter == nullptr && ddl_conv_stem_supported(p)) return ddl_launch_conv_stem(p, st);
+  if (use_ring && ddl_conv_c64_supported(p, MODE)) return ddl_launch_conv_c64(p, MODE, st);
   if (use_ring && ddl_conv_big_shape(p) != 0) {
     const int n0 = ddl_conv_big_split(p);
     if (n0 >= p.N) return ddl_launch_conv_big(p, MODE, st);

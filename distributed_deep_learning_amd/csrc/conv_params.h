@@ -65,6 +65,10 @@ int ddl_launch_conv_pring(ConvParams& p, int mode, hipStream_t stream);
 bool ddl_conv_stem_supported(const ConvParams& p);
 int ddl_launch_conv_stem(ConvParams& p, hipStream_t stream);
 
+// conv_c64.hip (3x3 / stride 1 / pad 1 over 64 -> 64 channels, forward and data gradient: filter and input patch in LDS)
+bool ddl_conv_c64_supported(const ConvParams& p, int mode);
+int ddl_launch_conv_c64(ConvParams& p, int mode, hipStream_t stream);
+
 // conv_big.hip (256 x 256 block tiles, two wave groups half a K-step apart, persistent: the MFMA-bound layers)
 int ddl_conv_big_shape(const ConvParams& p);
 int ddl_conv_big_split(const ConvParams& p);

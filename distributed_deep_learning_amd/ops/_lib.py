@@ -28,6 +28,8 @@ _SIGS = {
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp, _ll, _vp],
     "ddl_conv_wgrad_plan": [_i] * 11,
     "ddl_wgrad_halo_min_stages": [_i],
+    "ddl_conv_c64_min_stages": [_i],
+    "ddl_conv_c64_launches": [],
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "ddl_spin": [_ll, _vp],
     "ddl_stream_proxy": [_vp, _ll, C.c_int, C.c_int, _vp],
@@ -101,7 +103,7 @@ _SIGS = {
 }
 
 
-_LONG_RESULT = {"ddl_conv_wgrad_plan"}
+_LONG_RESULT = {"ddl_conv_wgrad_plan", "ddl_conv_c64_launches"}
 
 
 def _load():

@@ -329,6 +329,12 @@ def conv2d_dgrad(dy, w_crsk, in_hw, stride=1, pad=0, addend=None, addend_mask=No
 _WGRAD_PLANS: dict = {}
 
 
+def set_conv_c64_min_stages(n: int = 1024) -> None:
+    """Test hook: the smallest stage count for which ``csrc/conv_c64.hip`` (3x3 over 64 -> 64 channels, forward and data
+    gradient) is chosen instead of the ring kernels (default 1024 = four stages per block; 0: whenever the shape fits)."""
+    _lib.require().ddl_conv_c64_min_stages(int(n))
+
+
 def set_wgrad_halo_min_stages(n: int = 20) -> None:
     """Test hook: the shortest run of stages per block for which ``csrc/conv_wgrad.hip`` picks its halo kernel (default 20:
     small problems keep the ring kernels; 0: whenever the shape fits).  Clears the cached workspace plans."""
