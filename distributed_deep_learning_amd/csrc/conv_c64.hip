@@ -12,16 +12,21 @@
 //     reads them at a shifted position (one ds_read_b128 per B fragment, 512 contiguous bytes per wave-read);
 //   * the patch comes in two halves of 32 channels, each requested while the other is being multiplied (the filter
 //     leaves room for exactly one patch).
-// One block per CU (152 KiB of LDS), one wave per SIMD: written for an in-order machine like the halo filter gradient
+// One block per CU (158 KiB of LDS), one wave per SIMD: written for an in-order machine like the halo filter gradient
 // (csrc/conv_wgrad.hip): loads decoded once per kernel, one request per MFMA step, fragments one step ahead, MFMAs with
-// the accumulator tied in place.  Outputs leave straight from the accumulator layout (a lane holds 4 consecutive
-// channels of one pixel: four 8-byte stores per 16 x 64 tile fill whole 128-byte pixel rows), forward BatchNorm sums of
-// the ROUNDED values about per-lane pivots in registers, folded to the fp64 slab once per block.
+// the accumulator tied in place.  Outputs leave through wave-private LDS windows as full 128-byte pixel rows; forward
+// BatchNorm sums of the ROUNDED values about per-lane pivots in registers, folded to the fp64 slab once per block.
 // Data gradient = the same convolution over dy with the taps mirrored: the filter copy does the mirroring.
 #include "common.h"
 #include "conv_params.h"
 #include "host_util.h"
 #include <stdlib.h>
+
+// -DC64_ABL=bits compiles parts of the kernel out for timing (1: patch requests inside the loop, 2: MFMAs, 4: fragment
+// reads after the first step's, 8: output stores and statistics); the library is built with 0.
+#ifndef C64_ABL
+#define C64_ABL 0
+#endif
 
 namespace {
 
@@ -56,6 +61,8 @@ struct C64Geom {
 constexpr int C64_WBYTES = 9 * 64 * 64 * 2;      // the filter in LDS
 constexpr int C64_XS = 10;                       // LDS-DMA slots per wave and half patch
 constexpr int C64_MT = 7;                        // 16-pixel blocks per wave and stage
+constexpr int C64_OPITCH = 144;                  // bytes per pixel row of a wave's output window (conflict-free 8-byte writes)
+constexpr int C64_WIN = 16 * C64_OPITCH;
 
 template <int MODE, bool STATS>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, const C64Geom cg) {
@@ -129,16 +136,17 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, co
   const char* const wbase = smem + g * 1024 + col * 16;
 
   f32x4 acc[MT][4];
-  float s1[16], s2[16], kf[16];
+  float s1[8], s2[8], kf[8];
   if (STATS) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) { s1[q] = 0.f; s2[q] = 0.f; kf[q] = 0.f; }
+    for (int q = 0; q < 8; ++q) { s1[q] = 0.f; s2[q] = 0.f; kf[q] = 0.f; }
   }
+  char* const win = smem + C64_WBYTES + 2 * cg.half_bytes + 1024 + wid * C64_WIN;
   int npix = 0;
   bool have_pivot = false;
 
-  // one half of a stage: nine MFMA steps (taps) over 32 channels; fragments one step ahead; request slot t of the NEXT
-  // half (other buffer) goes out with step t
+  // one half of a stage: nine MFMA steps (taps) over 32 channels; fragments one step ahead; the requests of the NEXT
+  // half (other buffer) go out with the first two steps
   auto half = [&](int h, bool first) {
     const char* const ph = smem + C64_WBYTES + h * cg.half_bytes;
     bf16x8 a0[4], a1[4], b0[MT], b1[MT];
@@ -151,17 +159,21 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, co
       for (int i = 0; i < MT; ++i) b[i] = *reinterpret_cast<const bf16x8*>(ph + posb[i] + toff);
     };
     load(0, a0, b0);
+    if (C64_ABL & 4) load(1, a1, b1);
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       bf16x8 (&ac)[4] = (t & 1) ? a1 : a0;
       bf16x8 (&bc)[MT] = (t & 1) ? b1 : b0;
-      issue_slot(t);
-      if (t == 8) issue_slot(9);
-      if (t + 1 < 9) load(t + 1, (t & 1) ? a0 : a1, (t & 1) ? b0 : b1);
+      if (t < 2 && !(C64_ABL & 1)) {     // all ten requests behind the first two steps: the rest of the half is their time to land
+#pragma unroll
+        for (int k = 0; k < XS / 2; ++k) issue_slot(t * (XS / 2) + k);
+      }
+      if (t + 1 < 9 && !(C64_ABL & 4)) load(t + 1, (t & 1) ? a0 : a1, (t & 1) ? b0 : b1);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
+          if ((C64_ABL & 2) && !(first && t == 0)) { asm volatile("" :: "v"(ac[nb]), "v"(bc[i])); continue; }
           if (first && t == 0) c64_mfma_first(acc[i][nb], ac[nb], bc[i]);
           else                 c64_mfma(acc[i][nb], ac[nb], bc[i]);
         }
@@ -178,10 +190,10 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, co
     const int n = (int)fastdiv((unsigned)st, cg.div_nrb);
     const int p0 = (st - n * cg.nrb) * cg.TR;
     // ---- first half: its requests went out during the previous stage's second half, BEFORE that stage's output stores;
-    //      vector memory operations retire in issue order, so the stores (4 per pixel block) may stay in flight
-    if (stores == 4 * MT) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+    //      vector memory operations retire in issue order, so the stores (2 per pixel block) may stay in flight
+    if (stores == 2 * MT) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
     else                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    static_assert(4 * C64_MT == 28, "the counted wait above");
+    static_assert(2 * C64_MT == 14, "the counted wait above");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     begin_half(st, 1, true);
@@ -192,58 +204,67 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, co
     begin_half(min(st + 1, cg.nst - 1), 0, st + 1 < st_end);
     half(1, false);
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs have written the accumulators
-    // ---- outputs straight from the accumulator layout: lane = (4 channels g*4.. of block nb) x (pixel col)
+    // ---- outputs: each 16-pixel block goes through the wave's private LDS window ([pixel][64 channels], no block
+    //      barrier) and leaves as two full-line stores (8 pixels x 128 bytes each).  Storing straight from the
+    //      accumulator layout (a lane holds 4 channels of one pixel: four 8-byte stores per block) was measured at
+    //      2.3x the cost per byte (0.09 ms of a 0.28 ms layer, bench/c64_abl.sh).
     stores = 0;
     const int trv_px = min(cg.TR, p.OH - p0) * p.OW;            // pixels of the stage inside the image
     const size_t mrow0 = (size_t)(n * p.OH + p0) * p.OW;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
-      const int m = (wid * MT + i) * 16 + col;
-      if (m < trv_px) {                                         // per lane: a pixel block may straddle the last valid row
-        bf16_t* const o = p.out + (mrow0 + (size_t)m) * 64 + g * 4;
+      const int mb = (wid * MT + i) * 16;                        // first pixel of the block
+      if (mb < trv_px && !(C64_ABL & 8)) {                       // wave-uniform
 #pragma unroll
         for (int nb = 0; nb < 4; ++nb) {
           u32x2 pk;
           pk[0] = pack_bf16x2(acc[i][nb][0], acc[i][nb][1]);
           pk[1] = pack_bf16x2(acc[i][nb][2], acc[i][nb][3]);
-          *reinterpret_cast<u32x2*>(o + nb * 16) = pk;
-          if (STATS) {
-            float f[4];
-            f[0] = __uint_as_float(pk[0] << 16); f[1] = __uint_as_float(pk[0] & 0xffff0000u);
-            f[2] = __uint_as_float(pk[1] << 16); f[3] = __uint_as_float(pk[1] & 0xffff0000u);
-            if (!have_pivot) {
+          *reinterpret_cast<u32x2*>(win + col * C64_OPITCH + (nb * 16 + g * 4) * 2) = pk;
+        }
 #pragma unroll
-              for (int e = 0; e < 4; ++e) kf[nb * 4 + e] = f[e];
+        for (int pass = 0; pass < 2; ++pass) {
+          const int px = pass * 8 + (lane >> 3);
+          const u32x4 v = *reinterpret_cast<const u32x4*>(win + px * C64_OPITCH + (lane & 7) * 16);
+          if (mb + px < trv_px) {                                 // per lane: a block may straddle the last valid row
+            *reinterpret_cast<u32x4*>(p.out + (mrow0 + (size_t)(mb + px)) * 64 + (lane & 7) * 8) = v;
+            if (STATS) {
+              float f[8];
+              unpack8(v, f);
+              if (!have_pivot) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kf[q] = f[q];
+                have_pivot = true;
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) { const float d = f[q] - kf[q]; s1[q] += d; s2[q] += d * d; }
+              ++npix;
             }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = f[e] - kf[nb * 4 + e]; s1[nb * 4 + e] += d; s2[nb * 4 + e] += d * d; }
           }
         }
-        if (STATS) { have_pivot = true; ++npix; }
+        stores += 2;
       }
-      if ((wid * MT + i) * 16 < trv_px) stores += 4;            // wave-uniform count of store instructions
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the zero fills requested during the last stage
 
   if (STATS) {
-    // per-lane shifted fp32 sums -> plain fp64 sums; the 64 threads that hold a channel meet in LDS (over the filter)
+    // per-lane shifted fp32 sums -> plain fp64 sums (own pivot, own count); lanes with the same 8 channels meet in LDS
+    // (over the filter); one slab add per channel and block
     __syncthreads();
-    double* const red = reinterpret_cast<double*>(smem);        // [256 threads][2][16] fp64 = 64 KiB
+    double* const red = reinterpret_cast<double*>(smem);        // [256 threads][2][8] fp64 = 32 KiB
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
+    for (int q = 0; q < 8; ++q) {
       double sx, sxx;
       unshift_sums(s1[q], s2[q], kf[q], (double)npix, sx, sxx);
-      red[(tid * 2 + 0) * 16 + q] = sx;
-      red[(tid * 2 + 1) * 16 + q] = sxx;
+      red[(tid * 2 + 0) * 8 + q] = sx;
+      red[(tid * 2 + 1) * 8 + q] = sxx;
     }
     __syncthreads();
     if (tid < 128) {
       const int which = tid >> 6, ch = tid & 63;
-      const int cg4 = (ch & 15) >> 2, q = (ch >> 4) * 4 + (ch & 3);      // channel = nb*16 + g*4 + e  ->  lanes g, slot nb*4 + e
       double s = 0.0;
-      for (int w = 0; w < 4; ++w)
-        for (int c = 0; c < 16; ++c) s += red[((w * 64 + cg4 * 16 + c) * 2 + which) * 16 + q];
+      for (int t = ch >> 3; t < 256; t += 8) s += red[(t * 2 + which) * 8 + (ch & 7)];   // threads with lane % 8 == ch / 8
       const size_t sbase = (size_t)(blockIdx.x % DDL_BN_SLOTS) * 2;
       slab_add(p.stats, (sbase + which) * (size_t)p.OC + ch, s);
     }
@@ -259,7 +280,7 @@ bool c64_geom(const ConvParams& p, C64Geom& cg) {
   if ((2 * cg.NV + 3) / 4 > C64_XS) return false;
   cg.chunk_bytes = cg.NV * 1024;
   cg.half_bytes = 2 * cg.chunk_bytes;
-  if (C64_WBYTES + 2 * cg.half_bytes + 1024 > 160 * 1024) return false;
+  if (C64_WBYTES + 2 * cg.half_bytes + 1024 + 4 * C64_WIN > 160 * 1024) return false;
   cg.nrb = (p.OH + cg.TR - 1) / cg.TR;
   cg.nst = p.N * cg.nrb;
   cg.div_nrb = make_fastdiv((unsigned)cg.nrb);
@@ -307,7 +328,7 @@ int ddl_launch_conv_c64(ConvParams& p, int mode, hipStream_t stream) {
   int blocks = 256;
   cg.sps = (cg.nst + blocks - 1) / blocks;
   blocks = (cg.nst + cg.sps - 1) / cg.sps;
-  const int smem = C64_WBYTES + 2 * cg.half_bytes + 1024;
+  const int smem = C64_WBYTES + 2 * cg.half_bytes + 1024 + 4 * C64_WIN;
   ++g_c64_launches;
   if (mode == 1) return c64_launch<1, false>(p, cg, blocks, smem, stream);
   if (p.stats != nullptr) return c64_launch<0, true>(p, cg, blocks, smem, stream);
