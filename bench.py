@@ -40,7 +40,7 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # stock PyTorch-ROCm ResNet-50 (bench/stock_models.py) on the same MI355X, img/s per GPU, keyed by per-GPU batch
 # (256 / 512: round 2; 1000: round 3, same session as our own 14.37k img/s - profiles/r3_same_session_stock_proxy_rn18.txt;
-#  14.6k since the halo filter-gradient kernel, profiles/r3_wgrad_halo_kernel.txt)
+#  14.9k since the halo filter-gradient, stem and 64-channel 3x3 kernels, profiles/r3_*_kernel.txt)
 STOCK_PYTORCH_1GPU_IMG_S = {256: 6638.0, 512: 6794.3, 1000: 6960.5}
 
 
