@@ -208,6 +208,9 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(const ConvParams p, co
     //      barrier) and leaves as two full-line stores (8 pixels x 128 bytes each).  Storing straight from the
     //      accumulator layout (a lane holds 4 channels of one pixel: four 8-byte stores per block) was measured at
     //      2.3x the cost per byte (0.09 ms of a 0.28 ms layer, bench/c64_abl.sh).
+    //      Leaving this phase to the NEXT stage's first half (outputs rounded into 56 registers, one block per MFMA
+    //      step, stores and statistics dealt out between the MFMAs) was built and measured: forward 0.284 -> 0.288 ms, data
+    //      gradient 0.258 -> 0.245 ms - the layer sits at 0.9 GB of traffic (0.17 ms), not at its issue slots; not kept.
     stores = 0;
     const int trv_px = min(cg.TR, p.OH - p0) * p.OW;            // pixels of the stage inside the image
     const size_t mrow0 = (size_t)(n * p.OH + p0) * p.OW;

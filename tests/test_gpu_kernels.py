@@ -374,10 +374,11 @@ def test_wgrad_is_bit_reproducible_and_accumulates(N, C, H, K, R, stride, pad):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (5, 32, 32), (2, 16, 16), (3, 20, 112)])
+@pytest.mark.parametrize("N,H,W", [(3, 56, 56), (2, 28, 28), (5, 32, 32), (2, 16, 16), (3, 20, 112), (80, 56, 56), (300, 32, 32)])
 def test_conv3x3_c64_kernel_matches_fp32_and_the_ring_kernels(N, H, W):
     """csrc/conv_c64.hip (filter + input patch in LDS) is chosen from ~150 images at 56 x 56 on; the threshold is lifted
-    here.  Forward with and without BatchNorm sums, data gradient, ragged last row blocks, against fp32 and against the
+    here.  Forward with and without BatchNorm sums, data gradient, ragged last row blocks, three to four stages per
+    block in the two large cases (the counted wait that leaves a stage's stores in flight), against fp32 and against the
     ring kernels' bits (same products, same fp32 accumulation order up to the MFMA's own: compared to 1e-2 of a bf16 ulp's
     worth of the output scale)."""
     from distributed_deep_learning_amd.ops import kernels as K
