@@ -1006,6 +1006,9 @@ static int launch_wgrad_wide(WgradParams& p, hipStream_t stream, int capacity) {
 }
 
 static int g_halo_min_stages = 20;
+static long long g_halo_launches = 0;
+// Test hook: launches of the halo kernel so far (a parity test that silently ran the ring kernels proves nothing).
+extern "C" long long ddl_wgrad_halo_launches() { return g_halo_launches; }
 // Test hook: the smallest run of stages per block for which the halo kernel is chosen (0: whenever the shape fits).
 extern "C" void ddl_wgrad_halo_min_stages(int n) { g_halo_min_stages = n; }
 
@@ -1050,6 +1053,7 @@ static int launch_wgrad_halo(WgradParams& p, hipStream_t stream) {
   p.splits = (int)splits;
   p.m_per_split = hg.sps * hg.px;
   if (!wgrad_prepare(p)) return 0;
+  ++g_halo_launches;
   static SmemAttrOnce once;
   const int rc = once.ensure(reinterpret_cast<const void*>(&conv_wgrad_halo_kernel<WKS, WNS, R_, S_, TAPSPLIT, XS, NB>), 160 * 1024);
   if (rc != 0) return rc;

@@ -28,6 +28,7 @@ _SIGS = {
     "ddl_conv_wgrad": [_vp, _vp, _vp] + [_i] * 11 + [_vp, _ll, _vp],
     "ddl_conv_wgrad_plan": [_i] * 11,
     "ddl_wgrad_halo_min_stages": [_i],
+    "ddl_wgrad_halo_launches": [],
     "ddl_conv_c64_min_stages": [_i],
     "ddl_conv_c64_launches": [],
     "ddl_relu_bwd_bias_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -103,7 +104,7 @@ _SIGS = {
 }
 
 
-_LONG_RESULT = {"ddl_conv_wgrad_plan", "ddl_conv_c64_launches"}
+_LONG_RESULT = {"ddl_conv_wgrad_plan", "ddl_conv_c64_launches", "ddl_wgrad_halo_launches"}
 
 
 def _load():

@@ -412,6 +412,40 @@ def test_conv3x3_c64_kernel_matches_fp32_and_the_ring_kernels(N, H, W):
     assert float((dx.float() - dx_ring.float()).abs().max()) <= 0.02 * float(dref.abs().max())
 
 
+@pytest.mark.gpu
+def test_late_round3_kernels_run_at_their_shipped_thresholds():
+    """The other tests lift the size thresholds of the halo filter gradient and of the 64-channel 3x3 kernel; this one
+    leaves them alone and uses operands just big enough for the shipped selection (320 images of 256 x 14 x 14: 20 stages
+    per halo block; 160 images of 64 x 56 x 56: 1120 stages of the 64-channel kernel), checks through the launch counters
+    that those kernels ran, and compares with fp32."""
+    from distributed_deep_learning_amd.ops import _lib
+    from distributed_deep_learning_amd.ops import kernels as K
+    lib = _lib.require()
+    x = _rand_act((320, 256, 14, 14), 51)
+    dy = _rand_act((320, 256, 14, 14), 52)
+    h0 = lib.ddl_wgrad_halo_launches()
+    dw = K.conv2d_wgrad(dy, x, 3, 3, 1, 1)
+    assert lib.ddl_wgrad_halo_launches() == h0 + 1
+    ref = torch.nn.grad.conv2d_weight(x.float(), (256, 256, 3, 3), dy.float(), 1, 1)
+    _close(dw, ref, rtol=1e-2, atol=1e-2 * ref.abs().max().item(), what="halo wgrad at the shipped threshold")
+    del x, dy, dw, ref
+    x = _rand_act((160, 64, 56, 56), 53)
+    w = (torch.randn((64, 64, 3, 3), generator=torch.Generator().manual_seed(54)) / 24.0).to(_dev()).contiguous(memory_format=CL)
+    wk, wc = K.filter_repack(w)
+    wq = wk.permute(0, 3, 1, 2).float()
+    c0 = lib.ddl_conv_c64_launches()
+    y, st = K.conv2d_fwd(x, wk, 1, 1, want_stats=True)
+    dx = K.conv2d_dgrad(x, wc, (56, 56), 1, 1)
+    assert lib.ddl_conv_c64_launches() == c0 + 2
+    ref = F.conv2d(x[:8].float(), wq, None, 1, 1)
+    _close(y[:8], ref, what="c64 forward at the shipped threshold")
+    _close(y[-8:], F.conv2d(x[-8:].float(), wq, None, 1, 1), what="c64 forward, last images")
+    yf = y.float()
+    _close(K.slab_sums(st)[0], yf.sum((0, 2, 3)), rtol=1e-3, atol=1e-2 * max(1.0, yf.abs().max().item()), what="c64 fused sum")
+    dref = torch.nn.grad.conv2d_input((8, 64, 56, 56), wq, x[:8].float(), 1, 1)
+    _close(dx[:8], dref, what="c64 dgrad at the shipped threshold")
+
+
 HALO_CASES = [
     # N, C, H, W, K, R, pad: what csrc/conv_wgrad.hip's halo kernel is built for, at sizes a test can afford
     (3, 256, 14, 14, 256, 3, 1),       # one image per stage, 128-filter tiles, 8 channel slices
@@ -439,10 +473,13 @@ def test_halo_filter_gradient_matches_fp32(case, deterministic):
     dy = _rand_act((N, Kc, P, Q), 12)
     ref = torch.nn.grad.conv2d_weight(x.float(), (Kc, C, R, R), dy.float(), 1, pad)
     ring = K.conv2d_wgrad(dy, x, R, R, 1, pad)
+    from distributed_deep_learning_amd.ops import _lib
+    launches = _lib.require().ddl_wgrad_halo_launches()
     K.set_wgrad_halo_min_stages(0)
     state.set_deterministic(deterministic)
     try:
         dw = K.conv2d_wgrad(dy, x, R, R, 1, pad)
+        assert _lib.require().ddl_wgrad_halo_launches() == launches + 1
         again = K.conv2d_wgrad(dy, x, R, R, 1, pad)
         acc = torch.ones((Kc, R, R, C), dtype=torch.float32, device=_dev()).permute(0, 3, 1, 2)
         K.conv2d_wgrad(dy, x, R, R, 1, pad, out=acc)
